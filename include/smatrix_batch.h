@@ -1,0 +1,93 @@
+/*
+ * smatrix_batch.h -- additive batched entry points (no reference counterpart as
+ * functions; each applies the reference's per-call semantics, src/smatrix.c:174-256,
+ * to n (x,y[,value]) triples at once -- the form the HIP kernels consume).
+ *
+ * Contract (SURVEY.md 8a "batch semantics"):
+ *  - the final table state equals applying the n ops one by one in SOME order the
+ *    reference's threads could have produced; row sizes and `used` counters are
+ *    exactly the reference's (they do not depend on the order);
+ *  - incr/decr: out[i] is the value after op i in that order (exact for unique
+ *    keys; for duplicates the largest out equals the final value);
+ *  - set: duplicates of one (x,y) inside a batch resolve to the HIGHEST index;
+ *    out[i] = v[i];
+ *  - a batch of one op, or any stream applied one op per call, reproduces the
+ *    reference's table bytes slot for slot.
+ *
+ * Two flavours: host pointers (staged through HBM by the library) and `_dev`
+ * (pointers are device memory on the matrix's GPU; work is enqueued on
+ * `hip_stream` -- a hipStream_t passed as void*, NULL = the matrix's own stream --
+ * and the call returns after the result is complete on that stream).
+ * Return value: 0 on success; failures abort like the scalar API.
+ * n must be < 2^32.
+ */
+#ifndef SMATRIX_BATCH_H
+#define SMATRIX_BATCH_H
+
+#include "smatrix.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* op codes for smatrix_apply_batch* */
+enum { SMATRIX_OP_GET = 0, SMATRIX_OP_SET = 1, SMATRIX_OP_INCR = 2, SMATRIX_OP_DECR = 3 };
+
+int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x,
+                        const uint32_t* y, const uint32_t* v, uint32_t* out);
+int smatrix_get_batch(smatrix_t* self, size_t n, const uint32_t* x, const uint32_t* y, uint32_t* out);
+int smatrix_set_batch(smatrix_t* self, size_t n, const uint32_t* x, const uint32_t* y,
+                      const uint32_t* v, uint32_t* out);
+int smatrix_incr_batch(smatrix_t* self, size_t n, const uint32_t* x, const uint32_t* y,
+                       const uint32_t* v, uint32_t* out);
+int smatrix_decr_batch(smatrix_t* self, size_t n, const uint32_t* x, const uint32_t* y,
+                       const uint32_t* v, uint32_t* out);
+int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t* out);
+/* row r writes at most offsets[r+1]-offsets[r] pairs at ret + 2*offsets[r] (uint32 units),
+ * in table slot order; counts[r] = pairs written.  offsets has n+1 entries. */
+int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uint64_t* offsets,
+                         uint32_t* ret, uint32_t* counts);
+
+/* device-pointer flavours */
+int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d_x,
+                            const uint32_t* d_y, const uint32_t* d_v, uint32_t* d_out,
+                            void* hip_stream);
+int smatrix_rowlen_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x, uint32_t* d_out,
+                             void* hip_stream);
+int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,
+                             const uint64_t* d_offsets, uint32_t* d_ret, uint32_t* d_counts,
+                             void* hip_stream);
+
+/* ---- introspection (tests, bench) ---------------------------------------- */
+typedef struct {
+  uint64_t rows;            /* rows in the directory */
+  uint64_t dir_slots;       /* directory capacity */
+  uint64_t arena_units;     /* 128-byte units handed out (incl. retired blocks) */
+  uint64_t arena_mapped;    /* bytes of HBM mapped for row tables */
+  uint64_t batches;         /* write batches executed */
+  uint64_t rounds;          /* op-kernel rounds over all write batches */
+  uint64_t deferred_ops;    /* ops re-run after a structure change */
+  uint64_t rows_grown;      /* row doublings */
+  uint64_t dir_grown;       /* directory rebuilds */
+  /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
+   * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
+  double   kernel_ms[4];
+  uint64_t kernel_launches[4];
+  uint64_t kernel_ops[4];
+} smatrix_stats_t;
+
+void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
+/* on: time every round-0 op kernel with HIP events on its stream (adds one sync per
+ * batch); resets the kernel_* accumulators.  Also enabled by SMATRIX_PROFILE=1. */
+void smatrix_profile(smatrix_t* self, int on);
+/* returns 1 if the row exists; size = slots, used = rowlen */
+int smatrix_row_info(smatrix_t* self, uint32_t x, uint32_t* size, uint32_t* used);
+/* copies the row's raw {key,value} slots (slot order); returns its size, 0 if absent */
+uint32_t smatrix_row_slots(smatrix_t* self, uint32_t x, uint32_t* kv, uint32_t cap_slots);
+/* 1 if a HIP device is usable; the library never falls back to a CPU path */
+int smatrix_device_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,555 @@
+// smx_kernels.hpp -- gfx950 device code of the (x,y)->uint32 path.
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   directory  : power-of-two array of 16-byte DirSlot {meta, x, base, used};
+//                hash = murmur3 finaliser of x, linear probing, load <= 1/2.
+//                Replaces the reference's x-directory smatrix_cmap_t
+//                (src/smatrix.h:51-65, src/smatrix.c:598-741) -- its layout is
+//                not observable through the API, so it is free to differ.
+//   row tables : one block of 16*2^k 8-byte {key,value} cells per row in one
+//                contiguous arena, addressed in 128-byte units.  A row table is
+//                BIT-COMPATIBLE with the reference's smatrix_rmap_t data
+//                (src/smatrix.h:35-49): identity hash `y % size`, linear
+//                probing, empty == (0,0), growth x2 when `used > size/2` is
+//                seen by an insert (src/smatrix.c:343-416).  Keeping it makes
+//                rowlen/getrow order/file blocks identical to the reference.
+//
+// No locks: the reference's per-row spin RW lock (src/smatrix.c:843-889) is
+// replaced by 64-bit CAS slot claims + 32-bit atomics on the value word, and
+// structure changes (row creation, growth, directory growth) run in their own
+// launches between rounds of the op kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smx {
+
+// ---- layout -----------------------------------------------------------------
+
+struct DirSlot {
+  uint32_t meta;   // bit0 USED | bits 8..13 log2(row size) | bit 16 GROW pending
+  uint32_t x;      // row id
+  uint32_t base;   // row block, in 128-byte arena units (0 = not yet allocated)
+  uint32_t used;   // the reference's rmap->used
+};
+static_assert(sizeof(DirSlot) == 16, "DirSlot must be 16 bytes");
+
+constexpr uint32_t META_USED = 1u;
+constexpr uint32_t META_GROW = 1u << 16;
+constexpr uint32_t META_LG_SHIFT = 8;
+constexpr uint32_t ROW_FIRST_LG = 4;  // SMATRIX_RMAP_INITIAL_SIZE 16, src/smatrix.h:21
+constexpr uint32_t UNIT_BYTES = 128;  // 16 cells
+
+__host__ __device__ inline uint32_t meta_lg(uint32_t meta) { return (meta >> META_LG_SHIFT) & 63u; }
+__host__ __device__ inline uint64_t units_of_lg(uint32_t lg) { return 1ull << (lg - ROW_FIRST_LG); }
+
+enum Op : int { OP_GET = 0, OP_SET = 1, OP_INCR = 2, OP_DECR = 3 };
+
+// device-side control block, one per matrix
+struct Ctl {
+  uint32_t n_defer;      // ops deferred by the current op round
+  uint32_t n_tasks;      // rows flagged for growth by prep
+  uint32_t dir_used;     // rows in the directory
+  uint32_t dir_full;     // prep refused a row creation (directory at its limit)
+  uint64_t arena_next;   // bump pointer, units
+  uint64_t grow_units;   // units the flagged growths will need
+  uint32_t n_chunks;     // 64-slot chunks over all growth tasks (old tables)
+  uint32_t n_chunks_new; // same over the new tables
+  uint32_t arena_oom;    // an allocation did not fit (host maps more and reruns)
+  uint32_t pad;
+};
+
+struct GrowTask {
+  uint32_t dslot;        // directory slot index
+  uint32_t old_lg;
+  uint32_t old_base;
+  uint32_t new_base;
+  uint32_t count;        // non-empty cells moved (becomes `used`, src/smatrix.c:410)
+  uint32_t chunk0;       // first 64-slot chunk of the old table in the flat chunk space
+  uint32_t chunk0_new;   // same for the new table
+  uint32_t pad;
+};
+
+__device__ inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bU; h ^= h >> 13; h *= 0xc2b2ae35U; h ^= h >> 16;
+  return h;
+}
+
+__device__ inline uint64_t pack_cell(uint32_t key, uint32_t value) {
+  return (uint64_t)key | ((uint64_t)value << 32);   // little-endian {key,value}
+}
+__device__ inline uint32_t cell_key(uint64_t c) { return (uint32_t)c; }
+__device__ inline uint32_t cell_val(uint64_t c) { return (uint32_t)(c >> 32); }
+
+__device__ inline uint64_t ld_relaxed(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline uint64_t* row_cells(uint8_t* arena, uint32_t base) {
+  return reinterpret_cast<uint64_t*>(arena + (uint64_t)base * UNIT_BYTES);
+}
+
+// Directory lookup on a STABLE directory (no creation in flight): plain 16-byte loads.
+__device__ inline DirSlot* dir_find(DirSlot* dir, uint32_t dmask, uint32_t x, uint4* snap) {
+  uint32_t h = fmix32(x) & dmask;
+  for (;;) {
+    uint4 s = *reinterpret_cast<const uint4*>(&dir[h]);   // {meta, x, base, used}
+    if (!(s.x & META_USED)) return nullptr;
+    if (s.y == x) { *snap = s; return &dir[h]; }
+    h = (h + 1) & dmask;
+  }
+}
+
+// Wave-aggregated append of `idx` to a list (one atomic per wave).
+__device__ inline void list_push(uint32_t* counter, uint32_t* list, uint32_t idx, bool want) {
+  uint64_t m = __ballot(want);
+  if (m == 0) return;
+  uint32_t lane = __lane_id();
+  uint32_t leader = __ffsll((unsigned long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (want) list[base + __popcll(m & ((1ull << lane) - 1))] = idx;
+}
+
+// ---- op kernel ----------------------------------------------------------------
+//
+// One lane per op.  Restates smatrix_lookup + the per-op tail
+// (src/smatrix.c:174-185 get, :225-256 set/incr/decr, :258-304 lookup,
+//  :363-380 rmap_probe) on the HBM tables.  Writers that would have to create a
+// row, or to insert into a row that stands at the reference's growth threshold
+// (`used > size/2`, src/smatrix.c:346), are DEFERRED: the structure change is
+// made by prep/grow between rounds, exactly where the reference makes it.
+//
+//   idx   : nullptr for round 0 (op i = thread i), else the deferred op list
+//   cellp : for OP_SET, the global cell index each op resolved to (duplicates of
+//           one cell inside a batch are resolved highest-index-wins afterwards)
+template <int OP>
+__global__ __launch_bounds__(256) void k_apply(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer,
+    uint64_t* cellp) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = t < n;
+  uint32_t j = 0, X = 0, Y = 0, V = 0;
+  if (live) {
+    j = idx ? idx[t] : t;
+    X = xs[j];
+    Y = ys[j];
+    if (OP != OP_GET) V = vs[j];
+  }
+  bool deferred = false;
+  uint32_t result = 0;
+
+  if (live) {
+    uint4 s;
+    DirSlot* d = dir_find(dir, dmask, X, &s);
+    if (!d || s.z == 0) {
+      deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
+    } else {
+      const uint32_t lg = meta_lg(s.x);
+      const uint32_t mask = (1u << lg) - 1u;
+      uint64_t* cells = row_cells(arena, s.z);
+      uint32_t pos = Y & mask;
+      if (OP == OP_GET) {
+        // src/smatrix.c:369-377 then :299: hit iff the probed slot's key == y
+        for (uint32_t step = 0; step <= mask; step++) {
+          uint64_t c = cells[pos];
+          if (cell_key(c) == Y) { result = cell_val(c); break; }
+          if (c == 0) break;
+          pos = (pos + 1) & mask;
+        }
+      } else if (Y != 0) {
+        uint64_t c = cells[pos];
+        for (uint32_t steps = 0;;) {
+          if (cell_key(c) == Y) break;                       // found
+          if (c == 0) {
+            // insert: reserve a place in `used` first; the reference inserts only
+            // while used <= size/2 (src/smatrix.c:346), otherwise it grows first
+            uint32_t u = atomicAdd(&d->used, 1u);
+            if (u > (mask + 1u) / 2u) {
+              atomicSub(&d->used, 1u);
+              deferred = true;
+              break;
+            }
+            uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull,
+                                      (unsigned long long)pack_cell(Y, 0));
+            if (prev == 0) break;                            // claimed {y,0} (:354-356)
+            atomicSub(&d->used, 1u);                         // lost the slot: give back
+            c = prev;
+            continue;                                        // re-examine what is there now
+          }
+          if (++steps > mask) { deferred = true; break; }    // no empty cell at all: let prep grow it
+          pos = (pos + 1) & mask;
+          c = cells[pos];
+        }
+        if (!deferred) {
+          uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
+          if (OP == OP_INCR) result = atomicAdd(vp, V) + V;      // :241, wraps mod 2^32
+          else if (OP == OP_DECR) result = atomicSub(vp, V) - V; // :252
+          else { result = V; cellp[j] = (((uint64_t)s.z) << 4) + pos; }  // :230, resolved later
+        }
+      } else {
+        // y == 0 (quirk Q1, src/smatrix.c:297-303,:370-374): the first slot whose KEY
+        // field is 0 -- the row's own (0,v) entry or the first empty slot -- is a hit;
+        // nothing is inserted and `used` is not touched.  Done with a 64-bit CAS so
+        // that a concurrent claim of that empty slot by another key cannot be hit.
+        uint64_t c = ld_relaxed(&cells[pos]);
+        for (uint32_t guard = 0; guard < 4u * (mask + 1u); guard++) {
+          if (cell_key(c) == 0) {
+            uint32_t nv = OP == OP_INCR ? cell_val(c) + V : OP == OP_DECR ? cell_val(c) - V : V;
+            uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]),
+                                      (unsigned long long)c, (unsigned long long)pack_cell(0, nv));
+            if (prev == c) { result = nv; break; }
+            c = prev;
+            continue;
+          }
+          pos = (pos + 1) & mask;
+          c = ld_relaxed(&cells[pos]);
+        }
+        if (OP == OP_SET) cellp[j] = ~0ull;   // y==0 sets are applied in place
+      }
+    }
+    if (!deferred) out[j] = result;
+  }
+  if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
+}
+
+// ---- prep kernel --------------------------------------------------------------
+//
+// Runs over the ops the op kernel deferred, on a quiescent table:
+//  * creates missing rows (src/smatrix.c:641-662: 16 zeroed cells, used 0),
+//    refusing (op stays deferred) when the directory stands at its load limit;
+//  * flags a row for growth iff the op's key is ABSENT and the row stands at the
+//    reference's threshold -- the exact condition under which the reference's
+//    next insert would call smatrix_rmap_resize (src/smatrix.c:346-348).
+__global__ __launch_bounds__(256) void k_prep(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
+    uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
+    const uint32_t* __restrict__ ys, GrowTask* tasks) {
+  const uint32_t n = ctl->n_defer;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const uint32_t j = defer[t];
+    const uint32_t X = xs[j], Y = ys[j];
+    uint32_t h = fmix32(X) & dmask;
+    for (;;) {
+      uint64_t* w = reinterpret_cast<uint64_t*>(&dir[h]);   // {meta, x}
+      uint64_t mx = ld_relaxed(w);
+      if (mx == 0) {
+        // create the row: reserve a directory place, then claim {meta,x} in one CAS
+        uint32_t r = atomicAdd(&ctl->dir_used, 1u);
+        if (r >= dir_limit) {
+          atomicSub(&ctl->dir_used, 1u);
+          ctl->dir_full = 1;
+          break;
+        }
+        uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+        uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(w), 0ull,
+                                  (unsigned long long)want);
+        if (prev != 0) {
+          atomicSub(&ctl->dir_used, 1u);
+          continue;                       // somebody claimed this slot: look at it again
+        }
+        uint64_t u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), 1ull);
+        if (u >= arena_cap_units) { ctl->arena_oom = 1; break; }   // host guarantees this never fires
+        __hip_atomic_store(&dir[h].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if ((uint32_t)(mx >> 32) == X) {
+        // row exists.  base==0: created a moment ago in this very launch -> empty, nothing to flag
+        uint32_t base = __hip_atomic_load(&dir[h].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t meta = (uint32_t)mx;
+        if (base != 0 && Y != 0) {
+          const uint32_t lg = meta_lg(meta);
+          const uint32_t mask = (1u << lg) - 1u;
+          const uint64_t* cells = row_cells(arena, base);
+          uint32_t pos = Y & mask;
+          bool absent = true;                     // also when the table has no empty cell left
+          for (uint32_t step = 0; step <= mask; step++) {
+            uint64_t c = cells[pos];
+            if (cell_key(c) == Y) { absent = false; break; }
+            if (c == 0) break;
+            pos = (pos + 1) & mask;
+          }
+          uint32_t used = __hip_atomic_load(&dir[h].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (absent && used > (mask + 1u) / 2u) {
+            uint32_t old = atomicOr(&dir[h].meta, META_GROW);
+            if (!(old & META_GROW)) {
+              uint32_t k = atomicAdd(&ctl->n_tasks, 1u);
+              tasks[k].dslot = h;
+              tasks[k].old_lg = lg;
+              tasks[k].old_base = base;
+              atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units),
+                        (unsigned long long)units_of_lg(lg + 1));
+            }
+          }
+        }
+        break;
+      }
+      h = (h + 1) & dmask;
+    }
+  }
+}
+
+// ---- growth -------------------------------------------------------------------
+//
+// smatrix_rmap_resize (src/smatrix.c:383-416) doubles the table and re-inserts
+// every non-empty cell IN OLD SLOT ORDER.  The same final layout is produced in
+// parallel by priority linear probing: a cell's priority is its old slot index,
+// an arriving cell evicts a resident of lower priority (later old slot) and the
+// evicted cell moves on.  The fixed point is unique and equals the sequential
+// first-come-first-served layout (each cell sits in the first slot at/after its
+// home not taken by an earlier cell).  While moving, a new cell holds
+// {key, old_slot+1}; k_grow_finish swaps the index for the value.
+
+// one lane per task: allocate the new block, assign chunk ranges
+__global__ void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units) {
+  uint32_t n = ctl->n_tasks;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    GrowTask& k = tasks[t];
+    uint64_t units = units_of_lg(k.old_lg + 1);
+    uint64_t u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next),
+                           (unsigned long long)units);
+    if (u + units > arena_cap_units) ctl->arena_oom = 1;   // host guarantees this never fires
+    k.new_base = (uint32_t)u;
+    k.count = 0;
+    uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
+    uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
+    k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
+    k.chunk0_new = atomicAdd(&ctl->n_chunks_new, nc);
+  }
+}
+
+// chunk -> task maps, filled one wave per task
+__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks,
+                                                  uint32_t* map_old, uint32_t* map_new) {
+  uint32_t n = ctl->n_tasks;
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t t = wave; t < n; t += nwaves) {
+    const GrowTask k = tasks[t];
+    uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
+    uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
+    for (uint32_t c = lane; c < oc; c += 64) map_old[k.chunk0 + c] = t;
+    for (uint32_t c = lane; c < nc; c += 64) map_new[k.chunk0_new + c] = t;
+  }
+}
+
+// one wave per 64 old slots
+__global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tasks,
+                                                   const uint32_t* map_old, uint8_t* arena) {
+  uint32_t nchunks = ctl->n_chunks;
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
+    uint32_t t = map_old[ch];
+    GrowTask& k = tasks[t];
+    uint32_t old_size = 1u << k.old_lg;
+    uint32_t p = (ch - k.chunk0) * 64 + lane;
+    uint64_t cur = 0;
+    if (p < old_size) cur = row_cells(arena, k.old_base)[p];
+    bool ne = cur != 0;
+    uint64_t m = __ballot(ne);
+    if (lane == 0 && m) atomicAdd(&k.count, (uint32_t)__popcll(m));
+    if (ne) {
+      uint64_t* T = row_cells(arena, k.new_base);
+      uint32_t nmask = (2u << k.old_lg) - 1u;
+      uint32_t i = cell_key(cur) & nmask;
+      cur = pack_cell(cell_key(cur), p + 1);        // {key, priority}
+      uint64_t c = ld_relaxed(&T[i]);
+      for (;;) {
+        if (c == 0) {
+          uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&T[i]), 0ull,
+                                    (unsigned long long)cur);
+          if (prev == 0) break;
+          c = prev;
+          continue;
+        }
+        if (cell_val(c) > cell_val(cur)) {           // resident came later in old order: evict it
+          uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&T[i]),
+                                    (unsigned long long)c, (unsigned long long)cur);
+          if (prev != c) { c = prev; continue; }
+          cur = c;                                    // carry the evicted cell onward
+        }
+        i = (i + 1) & nmask;
+        c = ld_relaxed(&T[i]);
+      }
+    }
+  }
+}
+
+// one wave per 64 new slots: replace the carried old-slot index by the value
+__global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, const GrowTask* tasks,
+                                                     const uint32_t* map_new, uint8_t* arena) {
+  uint32_t nchunks = ctl->n_chunks_new;
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
+    uint32_t t = map_new[ch];
+    const GrowTask k = tasks[t];
+    uint32_t new_size = 2u << k.old_lg;
+    uint32_t q = (ch - k.chunk0_new) * 64 + lane;
+    if (q < new_size) {
+      uint64_t* T = row_cells(arena, k.new_base);
+      uint64_t c = T[q];
+      if (c != 0) {
+        uint64_t o = row_cells(arena, k.old_base)[cell_val(c) - 1];
+        T[q] = pack_cell(cell_key(c), cell_val(o));
+      }
+    }
+  }
+}
+
+// one lane per task: publish the new table (src/smatrix.c:408-410)
+__global__ void k_grow_commit(const Ctl* ctl, const GrowTask* tasks, DirSlot* dir) {
+  uint32_t n = ctl->n_tasks;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const GrowTask k = tasks[t];
+    DirSlot& d = dir[k.dslot];
+    d.meta = META_USED | ((k.old_lg + 1) << META_LG_SHIFT);
+    d.base = k.new_base;
+    d.used = k.count;
+  }
+}
+
+// ---- set: duplicates of one cell inside a batch resolve highest-index-wins ----
+// (the reference's threads would leave "some" value; the batch contract pins it)
+__global__ __launch_bounds__(256) void k_set_clear(uint32_t n, const uint64_t* cellp, uint8_t* arena) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n && cellp[j] != ~0ull)
+    reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = 0;
+}
+__global__ __launch_bounds__(256) void k_set_rank(uint32_t n, const uint64_t* cellp, uint8_t* arena) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n && cellp[j] != ~0ull)
+    atomicMax(&reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1], j + 1);
+}
+__global__ __launch_bounds__(256) void k_set_pick(uint32_t n, uint64_t* cellp, uint8_t* arena) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n && cellp[j] != ~0ull)
+    if (reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] != j + 1) cellp[j] = ~0ull;  // loser
+}
+__global__ __launch_bounds__(256) void k_set_store(uint32_t n, const uint64_t* cellp,
+                                                   const uint32_t* vs, uint8_t* arena) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n && cellp[j] != ~0ull)
+    reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = vs[j];
+}
+
+// ---- directory growth -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dir_rehash(const DirSlot* old, uint32_t old_size,
+                                                    DirSlot* dir, uint32_t dmask) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= old_size) return;
+  DirSlot s = old[p];
+  if (!(s.meta & META_USED)) return;
+  uint32_t h = fmix32(s.x) & dmask;
+  uint64_t want = (uint64_t)s.meta | ((uint64_t)s.x << 32);
+  for (;;) {
+    uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[h]), 0ull,
+                              (unsigned long long)want);
+    if (prev == 0) break;
+    h = (h + 1) & dmask;
+  }
+  dir[h].base = s.base;
+  dir[h].used = s.used;
+}
+
+// ---- rowlen / getrow ------------------------------------------------------------
+
+// src/smatrix.c:212-223: rmap->used, 0 for an absent row
+__global__ __launch_bounds__(256) void k_rowlen(DirSlot* dir, uint32_t dmask, uint32_t n,
+                                                const uint32_t* __restrict__ xs,
+                                                uint32_t* __restrict__ out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint4 s;
+  DirSlot* d = dir_find(dir, dmask, xs[t], &s);
+  out[t] = d ? s.w : 0;
+}
+
+// src/smatrix.c:189-210: one wave per row scans the table in slot order and
+// compacts the non-empty cells (ballot + prefix popcount keeps slot order).
+// Row r may receive at most offsets[r+1]-offsets[r] pairs; counts[r] = pairs written.
+__global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, uint8_t* arena,
+                                                uint32_t n, const uint32_t* __restrict__ xs,
+                                                const uint64_t* __restrict__ offsets,
+                                                uint64_t* __restrict__ ret,
+                                                uint32_t* __restrict__ counts) {
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    uint4 s;
+    DirSlot* d = dir_find(dir, dmask, xs[r], &s);
+    uint32_t written = 0;
+    if (d && s.z != 0) {
+      const uint64_t off = offsets[r];
+      const uint64_t cap64 = offsets[r + 1] - off;
+      const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+      const uint32_t size = 1u << meta_lg(s.x);
+      const uint64_t* cells = row_cells(arena, s.z);
+      for (uint32_t p0 = 0; p0 < size && written < cap; p0 += 64) {
+        uint32_t p = p0 + lane;
+        uint64_t c = p < size ? cells[p] : 0;
+        bool ne = c != 0;
+        uint64_t m = __ballot(ne);
+        uint32_t rank = written + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (ne && rank < cap) ret[off + rank] = c;
+        written += (uint32_t)__popcll(m);
+      }
+      if (written > cap) written = cap;
+    }
+    if (lane == 0) counts[r] = written;
+  }
+}
+
+// ---- debug / export helpers -------------------------------------------------------
+__global__ void k_row_info(DirSlot* dir, uint32_t dmask, uint32_t x, uint32_t* out4) {
+  uint4 s;
+  DirSlot* d = dir_find(dir, dmask, x, &s);
+  out4[0] = d ? 1 : 0;
+  out4[1] = d ? 1u << meta_lg(s.x) : 0;
+  out4[2] = d ? s.w : 0;
+  out4[3] = d ? s.z : 0;
+}
+
+// ---- stream generator (include/smx_stream.h) -----------------------------------------
+__device__ inline uint64_t splitmix_at(uint64_t seed, uint64_t j) {
+  uint64_t z = seed + (j + 1) * 0x9e3779b97f4a7c15ULL;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+
+__device__ inline uint32_t draw_id(int dist, uint32_t n_ids, const double* cdf, int scramble, uint64_t r) {
+  uint32_t id;
+  if (dist == 0) {
+    id = 1u + (uint32_t)(r % n_ids);
+  } else {
+    double u = (double)(r >> 11) * 0x1.0p-53;
+    uint32_t lo = 0, hi = n_ids - 1;
+    while (lo < hi) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if (cdf[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    id = lo + 1;
+  }
+  return scramble ? fmix32(id) : id;
+}
+
+__global__ __launch_bounds__(256) void k_stream_fill(int dist, uint64_t seed, uint32_t n_ids,
+                                                     const double* cdf, int scramble, uint64_t first,
+                                                     uint64_t n, uint32_t* x, uint32_t* y) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t op = first + i;
+  x[i] = draw_id(dist, n_ids, cdf, scramble, splitmix_at(seed, 2 * op));
+  y[i] = draw_id(dist, n_ids, cdf, scramble, splitmix_at(seed, 2 * op + 1));
+}
+
+}  // namespace smx

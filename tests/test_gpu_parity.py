@@ -1,0 +1,330 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the golden vectors of the
+real reference and against the oracle on the same seeded inputs.  Bit-exact throughout
+(uint32 arithmetic); layouts are compared slot for slot wherever the call pattern is
+sequential, and as (size, used, sorted cells) for batches (see include/smatrix_batch.h)."""
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+from libsmatrix_amd.stream import Stream
+from tests import replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    from tests.gpu_adapter import GpuMatrix
+    import libsmatrix_amd
+    assert libsmatrix_amd.device_available(), "no HIP device: the product has no CPU fallback"
+    return GpuMatrix
+
+
+def sha(a):
+    return hashlib.sha256(np.asarray(a).astype("<u4").tobytes()).hexdigest()
+
+
+def per_key_sorted(x, y, ret):
+    k = x.astype(np.uint64) << 32 | y.astype(np.uint64)
+    o = np.lexsort((ret, k))
+    return k[o], ret[o]
+
+
+def state_equal(g, o, rows, exact_layout):
+    for x in rows:
+        gi, oi = g.row_info(x), o.row_info(x)
+        assert gi == oi, ("row_info", x, gi, oi)
+        a, b = np.asarray(g.row_slots(x)), np.asarray(o.row_slots(x))
+        if exact_layout:
+            assert (a == b).all(), ("layout", x)
+        else:
+            ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
+            ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
+            assert ka.shape == kb.shape and (ka == kb).all(), ("content", x)
+            # and the table must be a valid `key % size` linear-probe layout (src/smatrix.c:363-380)
+            size = a.shape[0]
+            for p in np.nonzero(a[:, 0])[0]:
+                q = int(a[p, 0]) % size
+                while q != p:
+                    assert a[q, 0] != 0 or a[q, 1] != 0, ("probe chain broken", x, int(a[p, 0]))
+                    q = (q + 1) % size
+
+
+# ---------------------------------------------------------------------------
+def test_quirks_transcript_scalar_abi(G, golden):
+    """every op a scalar C-ABI call: table bytes identical to the reference's"""
+    m = G()
+    bad = replay.replay_quirks(m, golden("quirks")["transcript"])
+    m.close()
+    assert not bad, "\n".join(bad)
+
+
+def test_java_suite(G, golden):
+    """src/java/test/TestSparseMatrix.java:22-131 on one shared handle; the 10^6-op loops go
+    through the batched API, the rest through the scalar ABI"""
+    g = golden("java_suite")
+    m = G()
+    m.set(42, 23, 17); assert m.get(42, 23) == 17
+    m.set(4231, 2634, 0); m.incr(4231, 2634, 1); assert m.get(4231, 2634) == 1
+    m.set(1231, 2634, 0); m.incr(1231, 2634, 1); m.incr(1231, 2634, 5); assert m.get(1231, 2634) == 6
+    n, i = np.meshgrid(np.arange(1000, dtype=np.uint32), np.arange(1000, dtype=np.uint32), indexing="ij")
+    xs, ys = i.ravel(), n.ravel()
+    out = m.apply(1, xs, ys, np.full(xs.size, 34, np.uint32))
+    assert (out == 34).all()
+    assert (m.apply(0, xs, ys) == 34).all()
+    r = np.arange(1000, dtype=np.uint32)
+    for col, key in ((42, "case5_rowlen_42"), (85, "case6_rowlen_85"), (83, None)):
+        for x in r.tolist()[:50]:
+            m.incr(x, col, 1)                       # scalar calls
+        m.apply(2, r[50:], np.full(950, col, np.uint32), np.ones(950, np.uint32))
+        if key:
+            assert m.rowlen(col) == g[key]
+    assert m.getrow(85, m.rowlen(85) * 8).shape[0] == g["case6_getrow_85_pairs"] == 1000
+    full = m.m.getRow(83)
+    assert len(full) == g["case7_getrow_83_pairs"] and len(m.m.getRow(83, 230)) == 230
+    assert m.getrow(85, 16 * 8).tolist() == g["row_85_first_pairs"]
+    rows = sorted(set(range(1000)) | {4231, 1231})
+    assert len(rows) == g["summary"]["rows"]
+    assert replay.content_digest(m, rows) == g["summary"]["content_sha256"]
+    # keys 0..999 in 2048-slot rows sit at their home slots whatever the order: layout is unique
+    assert replay.layout_digest(m, rows) == g["summary"]["layout_sha256"]
+    m.close()
+
+
+@pytest.mark.parametrize("scalar", [True, False])
+def test_golden_streams_small(G, golden, scalar):
+    g = golden("streams")
+    for case in g["cases"]:
+        sm = case["small"]
+        gen = Stream(case["dist"], g["seed"], case["n_ids"], g["zipf_s"], case["scramble"])
+        x, y = gen.fill(0, sm["n"])
+        m = G(scalar=scalar)
+        ret = m.apply(2, x, y, np.ones(sm["n"], np.uint32))
+        want = np.array(sm["incr_returns"], dtype=np.uint32)
+        if scalar:
+            assert (ret == want).all(), case["name"]
+        else:
+            a, b = per_key_sorted(x, y, ret), per_key_sorted(x, y, want)
+            assert (a[1] == b[1]).all(), case["name"]
+        assert m.sum_get(x, y) == sm["sum_get"]
+        rows = sorted(set(x.tolist()))
+        assert len(rows) == sm["summary"]["rows"]
+        assert replay.content_digest(m, rows) == sm["summary"]["content_sha256"], case["name"]
+        if scalar:
+            assert replay.layout_digest(m, rows) == sm["summary"]["layout_sha256"], case["name"]
+            d = np.arange(0, sm["n"], 3)
+            assert sha(m.apply(3, x[d], y[d], np.ones(d.size, np.uint32))) == sm["decr_returns_sha256"]
+            s = np.arange(0, sm["n"], 7)
+            assert sha(m.apply(1, x[s], y[s], (s % 5).astype(np.uint32))) == sm["set_returns_sha256"]
+            assert replay.layout_digest(m, rows) == sm["after_mixed"]["layout_sha256"]
+            assert m.sum_get(x, y) == sm["after_mixed_sum_get"]
+        m.close()
+        gen.close()
+
+
+def test_golden_streams_big_batched(G, golden):
+    g = golden("streams")
+    for case in g["cases"]:
+        big = case["big"]
+        gen = Stream(case["dist"], g["seed"], case["n_ids"], g["zipf_s"], case["scramble"])
+        x, y = gen.fill(0, big["n"])
+        m = G()
+        half = big["n"] // 2
+        m.apply(2, x[:half], y[:half], np.ones(half, np.uint32))          # two batches
+        m.apply(2, x[half:], y[half:], np.ones(big["n"] - half, np.uint32))
+        assert m.sum_get(x, y) == big["sum_get"], case["name"]
+        rows = np.unique(x).tolist()
+        assert len(rows) == big["summary"]["rows"]
+        assert replay.content_digest(m, rows) == big["summary"]["content_sha256"], case["name"]
+        m.close()
+        gen.close()
+
+
+@pytest.mark.parametrize("seed,nx,ny,n", [(1, 50, 40, 20000), (2, 3, 2000, 20000), (3, 5000, 5000, 60000),
+                                          (4, 1, 1 << 30, 30000), (5, 200000, 64, 200000)])
+def test_random_mixed_batches_vs_oracle(G, oracle_mod, seed, nx, ny, n):
+    """runs of one op kind (the batch API's unit) with y=0 / value 0 / wrap-around included;
+    duplicate keys inside a batch are frequent"""
+    rng = np.random.default_rng(seed)
+    g, o = G(), oracle_mod.Oracle()
+    for rnd in range(6):
+        x = rng.integers(0, nx, n, dtype=np.uint32)
+        y = rng.integers(1, ny, n, dtype=np.uint32)       # y >= 1: the order-independent domain
+        v = rng.integers(0, 4, n, dtype=np.uint32)
+        v[rng.random(n) < 0.01] = 0xFFFFFFFF
+        op = (2, 3, 1, 2, 0, 3)[rnd]
+        a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
+        if op == 0:
+            assert (a == b).all()
+        elif op == 1:
+            assert (a == v).all() and (b == v).all()
+        else:
+            # returns are "value after the op in some serialisation": the per-key multiset is NOT
+            # order independent for mixed increments, but the final value is
+            last = per_key_sorted(x, y, np.arange(n, dtype=np.uint32))
+            del last
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), (seed, rnd)
+    rows = o.list_rows().tolist()
+    state_equal(g, o, rows[:400], exact_layout=False)
+    lens_g = g.m.rowlen_batch(np.array(rows, dtype=np.uint32))
+    lens_o = np.array([o.rowlen(r) for r in rows], dtype=np.uint32)
+    assert (lens_g == lens_o).all()
+    g.close(); o.close()
+
+
+def test_y_zero_quirks_sequential(G, oracle_mod):
+    """y=0 (Q1-Q3) through the scalar ABI in a fixed order: bit-identical incl. `used`"""
+    rng = np.random.default_rng(11)
+    g, o = G(), oracle_mod.Oracle()
+    for _ in range(3000):
+        x = int(rng.integers(0, 6)); y = int(rng.choice([0, 0, 16, 32, 48, 5, 21, int(rng.integers(0, 200))]))
+        v = int(rng.integers(0, 3)); op = ("set", "incr", "decr", "get")[int(rng.integers(0, 4))]
+        args = (x, y) if op == "get" else (x, y, v)
+        assert getattr(g, op)(*args) == getattr(o, op)(*args)
+    state_equal(g, o, o.list_rows().tolist(), exact_layout=True)
+    g.close(); o.close()
+
+
+def test_getrow_and_rowlen_batch(G, oracle_mod):
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 400, 150000, dtype=np.uint32)
+    y = rng.integers(1, 1 << 20, 150000, dtype=np.uint32)
+    g, o = G(), oracle_mod.Oracle()
+    g.apply(2, x, y, np.ones(x.size, np.uint32)); o.apply(2, x, y, np.ones(x.size, np.uint32))
+    xs = np.arange(0, 420, dtype=np.uint32)                # includes absent rows
+    lens = g.m.rowlen_batch(xs)
+    assert lens.tolist() == [o.rowlen(int(r)) for r in xs]
+    off, pairs, cnt = g.m.getrow_batch(xs)
+    for r in range(xs.size):
+        mine = pairs[off[r]: off[r] + cnt[r]]
+        theirs = o.getrow(int(xs[r]))
+        assert cnt[r] == theirs.shape[0]
+        a = mine[np.lexsort((mine[:, 1], mine[:, 0]))]; b = theirs[np.lexsort((theirs[:, 1], theirs[:, 0]))]
+        assert (a == b).all()
+        slots = g.row_slots(int(xs[r]))
+        if slots is not None:                               # slot order
+            ne = slots[(slots[:, 0] != 0) | (slots[:, 1] != 0)]
+            assert (mine == ne).all()
+    # truncation: capacity 3 pairs per row; scalar ABI: ret_len in BYTES, rounds up (S4)
+    off, pairs, cnt = g.m.getrow_batch(xs, caps=np.full(xs.size, 3, np.uint64))
+    assert cnt.tolist() == [min(3, o.rowlen(int(r))) for r in xs]
+    for rl, want in ((24, 3), (20, 3), (7, 1), (0, 1)):
+        assert g.getrow(5, rl).shape[0] == want == o.getrow(5, rl).shape[0]
+    assert g.getrow(4000, 64).shape[0] == 0
+    g.close(); o.close()
+
+
+def test_set_batch_duplicates_highest_index_wins(G):
+    m = G()
+    x = np.array([1, 1, 1, 2, 1, 2], dtype=np.uint32); y = np.array([5, 5, 6, 5, 5, 5], dtype=np.uint32)
+    v = np.array([10, 11, 12, 13, 14, 15], dtype=np.uint32)
+    assert (m.apply(1, x, y, v) == v).all()
+    assert (m.get(1, 5), m.get(1, 6), m.get(2, 5)) == (14, 12, 15)
+    n = 100000
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 50, n, dtype=np.uint32); y = rng.integers(1, 50, n, dtype=np.uint32)
+    v = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    m.apply(1, x, y, v)
+    k = x.astype(np.uint64) << 32 | y
+    last = {}
+    for i in range(n):
+        last[int(k[i])] = int(v[i])
+    ks = np.array(list(last.keys()), dtype=np.uint64)
+    got = m.apply(0, (ks >> 32).astype(np.uint32), (ks & 0xFFFFFFFF).astype(np.uint32))
+    assert got.tolist() == list(last.values())
+    m.close()
+
+
+def test_full_size_batch_properties(G):
+    """BASELINE config-2 batch size (2^24 ops of the Zipf(1.1) scrambled stream): size-independent
+    properties instead of the oracle -- every get equals the key's multiplicity so far, the
+    largest incr return per key equals it too, sum(rowlen) == number of distinct cells"""
+    n = 1 << 24
+    gen = Stream("zipf", 12345, 1000000, 1.1, 1)
+    x, y = gen.fill(0, n)
+    m = G()
+    ret = m.apply(2, x, y, np.ones(n, np.uint32))
+    k = x.astype(np.uint64) << 32 | y
+    uk, inv, cnt = np.unique(k, return_inverse=True, return_counts=True)
+    got = m.apply(0, x, y)
+    assert (got == cnt[inv]).all()
+    mx = np.zeros(uk.size, dtype=np.uint32)
+    np.maximum.at(mx, inv, ret)
+    assert (mx == cnt).all()
+    assert int(ret.astype(np.uint64).sum()) == int((cnt.astype(np.uint64) * (cnt + 1) // 2).sum())
+    rows = np.unique(x)
+    assert int(m.m.rowlen_batch(rows).astype(np.uint64).sum()) == uk.size
+    st = m.stats()
+    assert st["rows"] == rows.size
+    # decr everything back: all cells 0, rowlen unchanged (S3)
+    m.apply(3, x, y, np.ones(n, np.uint32))
+    assert not m.apply(0, x, y).any()
+    assert int(m.m.rowlen_batch(rows).astype(np.uint64).sum()) == uk.size
+    m.close()
+
+
+def test_dense_ids_long_probe_chains(G, oracle_mod):
+    """dense Zipf ids: identity hash + linear probing clusters; same answers"""
+    gen = Stream("zipf", 99, 200000, 1.1, 0)
+    x, y = gen.fill(0, 400000)
+    g, o = G(), oracle_mod.Oracle()
+    g.apply(2, x, y, np.ones(x.size, np.uint32)); o.apply(2, x, y, np.ones(x.size, np.uint32))
+    assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
+    rows = o.list_rows()
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    g.close(); o.close()
+
+
+def test_threads_on_one_handle(G):
+    """README.md:113,120 of the reference: all data calls are thread-safe on one handle"""
+    m = G()
+    T, N = 8, 300
+
+    def work(t):
+        for i in range(N):
+            m.incr(i % 17, 1 + (i % 29), 1)
+            m.get(i % 17, 1 + (i % 29))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [t.start() for t in th]; [t.join() for t in th]
+    total = sum(m.get(a, b) for a in range(17) for b in range(1, 30))
+    assert total == T * N
+    m.close()
+
+
+def test_file_roundtrip_and_cross_open(G, oracle_mod, tmp_path, golden):
+    """file-backed mode: close is the flush barrier; files are interchangeable with the oracle's
+    (and with the real reference's where oracle/_ref is present)"""
+    g = golden("fileformat")
+    path = str(tmp_path / "g.smx")
+    m = G(path)
+    for op, *a in g["ops"]:
+        getattr(m, op)(*a)
+    m.close()
+    readers = [oracle_mod.Oracle] + ([oracle_mod.Reference] if oracle_mod.have_reference() else [])
+    for R in readers:
+        r = R(path)
+        for op, a, want in g["after_reopen"]:
+            assert getattr(r, op)(*a) == want, (R.__name__, op, a)
+        r.close()
+    m = G(path)
+    for op, a, want in g["after_reopen"]:
+        assert getattr(m, op)(*a) == want, ("gpu", op, a)
+    m.close()
+    # bigger: written by each implementation, read by the GPU library, extended, read back
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 3000, 200000, dtype=np.uint32); y = rng.integers(1, 30000, 200000, dtype=np.uint32)
+    v = rng.integers(1, 9, 200000, dtype=np.uint32)
+    for W in readers:
+        p2 = str(tmp_path / ("w_%s.smx" % W.__name__))
+        w = W(p2); w.apply(2, x, y, v); want = w.apply(0, x, y)
+        lens = [w.rowlen(i) for i in range(3000)]; w.close()
+        m = G(p2)
+        assert (m.apply(0, x, y) == want).all()
+        assert m.m.rowlen_batch(np.arange(3000, dtype=np.uint32)).tolist() == lens
+        m.apply(2, x, y + 40000, v); want2 = m.apply(0, x, y + 40000)
+        m.close()
+        w = W(p2)
+        assert (w.apply(0, x, y) == want).all() and (w.apply(0, x, y + 40000) == want2).all()
+        w.close()
