@@ -67,7 +67,7 @@ struct GrowTask {
   uint32_t count;        // non-empty cells moved (becomes `used`, src/smatrix.c:410)
   uint32_t chunk0;       // first 64-slot chunk of the old table in the flat chunk space
   uint32_t chunk0_new;   // same for the new table
-  uint32_t pad;
+  uint32_t dup;          // the old table holds one key twice (see k_grow_fixdup)
 };
 
 __device__ inline uint32_t fmix32(uint32_t h) {
@@ -122,8 +122,7 @@ __device__ inline void list_push(uint32_t* counter, uint32_t* list, uint32_t idx
 // made by prep/grow between rounds, exactly where the reference makes it.
 //
 //   idx   : nullptr for round 0 (op i = thread i), else the deferred op list
-//   cellp : for OP_SET, the global cell index each op resolved to (duplicates of
-//           one cell inside a batch are resolved highest-index-wins afterwards)
+//   cellp : unused here (set duplicates are resolved after the rounds, k_set_locate)
 template <int OP>
 __global__ __launch_bounds__(256) void k_apply(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(256) void k_apply(
           uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
           if (OP == OP_INCR) result = atomicAdd(vp, V) + V;      // :241, wraps mod 2^32
           else if (OP == OP_DECR) result = atomicSub(vp, V) - V; // :252
-          else { result = V; cellp[j] = (((uint64_t)s.z) << 4) + pos; }  // :230, resolved later
+          else { result = V; atomicExch(vp, V); }                  // :230 (duplicates: see k_set_locate)
         }
       } else {
         // y == 0 (quirk Q1, src/smatrix.c:297-303,:370-374): the first slot whose KEY
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(256) void k_apply(
           pos = (pos + 1) & mask;
           c = ld_relaxed(&cells[pos]);
         }
-        if (OP == OP_SET) cellp[j] = ~0ull;   // y==0 sets are applied in place
       }
     }
     if (!deferred) out[j] = result;
@@ -314,6 +312,7 @@ __global__ void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units)
     if (u + units > arena_cap_units) ctl->arena_oom = 1;   // host guarantees this never fires
     k.new_base = (uint32_t)u;
     k.count = 0;
+    k.dup = 0;
     uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
     uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
     k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
@@ -382,7 +381,7 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
 }
 
 // one wave per 64 new slots: replace the carried old-slot index by the value
-__global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, const GrowTask* tasks,
+__global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* tasks,
                                                      const uint32_t* map_new, uint8_t* arena) {
   uint32_t nchunks = ctl->n_chunks_new;
   uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -399,8 +398,43 @@ __global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, const GrowT
       if (c != 0) {
         uint64_t o = row_cells(arena, k.old_base)[cell_val(c) - 1];
         T[q] = pack_cell(cell_key(c), cell_val(o));
+        // a key that a probe from its home finds in ANOTHER slot first is a duplicate
+        // (keys are stable during this kernel, only value words change)
+        uint32_t nmask = new_size - 1u, i = cell_key(c) & nmask;
+        while (i != q && cell_key(T[i]) != cell_key(c)) i = (i + 1) & nmask;
+        if (i != q) tasks[t].dup = 1;
       }
     }
+  }
+}
+
+// A row table can hold one key twice: y=0 writes may turn the uncounted (0,v) cell back
+// into an empty one (quirk Q1/Q3) and so cut a probe chain, after which the key behind the
+// cut is inserted again (the same happens after a reload that dropped a value-0 key, Q4).
+// smatrix_rmap_resize merges such twins -- the second one finds the first through
+// rmap_insert, keeps its slot and overwrites its value (src/smatrix.c:353-357,:401-402).
+// Priority probing cannot express the merge, so these (rare) rows are redone here the
+// reference's way: one lane, old slot order.
+__global__ void k_grow_fixdup(const Ctl* ctl, GrowTask* tasks, uint8_t* arena) {
+  uint32_t n = ctl->n_tasks;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    GrowTask& k = tasks[t];
+    if (!k.dup) continue;
+    const uint32_t old_size = 1u << k.old_lg, nmask = 2u * old_size - 1u;
+    const uint64_t* O = row_cells(arena, k.old_base);
+    uint64_t* T = row_cells(arena, k.new_base);
+    for (uint32_t q = 0; q <= nmask; q++) T[q] = 0;
+    uint32_t used = 0;
+    for (uint32_t p = 0; p < old_size; p++) {
+      const uint64_t c = O[p];
+      if (c == 0) continue;
+      const uint32_t key = cell_key(c);
+      uint32_t i = key & nmask;
+      while (cell_key(T[i]) != key && T[i] != 0) i = (i + 1) & nmask;   // :363-380
+      if (cell_key(T[i]) == 0 || cell_key(T[i]) != key) used++;          // :353-354
+      T[i] = c;
+    }
+    k.count = used;
   }
 }
 
@@ -418,6 +452,30 @@ __global__ void k_grow_commit(const Ctl* ctl, const GrowTask* tasks, DirSlot* di
 
 // ---- set: duplicates of one cell inside a batch resolve highest-index-wins ----
 // (the reference's threads would leave "some" value; the batch contract pins it)
+// After the rounds (structure final): where does each set's cell live?  y==0 sets were
+// applied in place (quirk Q1 path) and take no part.
+__global__ __launch_bounds__(256) void k_set_locate(DirSlot* dir, uint32_t dmask, uint8_t* arena,
+                                                    uint32_t n, const uint32_t* __restrict__ xs,
+                                                    const uint32_t* __restrict__ ys, uint64_t* cellp) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint64_t where = ~0ull;
+  const uint32_t Y = ys[j];
+  uint4 s;
+  DirSlot* d = Y ? dir_find(dir, dmask, xs[j], &s) : nullptr;
+  if (d && s.z) {
+    const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
+    const uint64_t* cells = row_cells(arena, s.z);
+    uint32_t pos = Y & mask;
+    for (uint32_t step = 0; step <= mask; step++) {
+      uint64_t c = cells[pos];
+      if (cell_key(c) == Y) { where = (((uint64_t)s.z) << 4) + pos; break; }
+      if (c == 0) break;
+      pos = (pos + 1) & mask;
+    }
+  }
+  cellp[j] = where;
+}
 __global__ __launch_bounds__(256) void k_set_clear(uint32_t n, const uint64_t* cellp, uint8_t* arena) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n && cellp[j] != ~0ull)

@@ -75,6 +75,7 @@ struct Arena {
       (void)hipGetLastError();
       return;
     }
+    g = std::max<size_t>(g, 2u << 20);   // keep chunks 2 MiB aligned (the probe reports 4 KiB)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     // a row base is a 32-bit count of 128-byte units: 512 GiB addressable
@@ -108,7 +109,9 @@ struct Arena {
       ad.location.type = hipMemLocationTypeDevice;
       ad.location.id = device;
       ad.flags = hipMemAccessFlagsProtReadWrite;
-      HIP_OK(hipMemSetAccess(base + mapped, add, &ad, 1));
+      // ROCm 7.2: access must be set from the start of the reservation (a sub-range
+      // starting at the new chunk returns hipErrorInvalidValue; tools/probe/vmm.cpp)
+      HIP_OK(hipMemSetAccess(base, mapped + add, &ad, 1));
       HIP_OK(hipMemsetAsync(base + mapped, 0, add, st));
       chunks.push_back({h, add});
       mapped += add;
@@ -283,6 +286,8 @@ void grow_rows(Matrix* m, hipStream_t s) {
                      dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
                      dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
+  hipLaunchKernelGGL(k_grow_fixdup, dim3(std::min<uint32_t>(blocks_for(nt, 64), 1024)), dim3(64), 0, s,
+                     m->d_ctl, m->tasks.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir);
   HIP_OK(hipGetLastError());
@@ -331,6 +336,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
 
   if (op == OP_SET) {
     dim3 g(blocks_for(n)), b(256);
+    hipLaunchKernelGGL(k_set_locate, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y,
+                       m->cellp.p);
     hipLaunchKernelGGL(k_set_clear, g, b, 0, s, n, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_rank, g, b, 0, s, n, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_pick, g, b, 0, s, n, m->cellp.p, m->arena.base);
