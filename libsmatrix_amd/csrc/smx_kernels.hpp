@@ -123,95 +123,212 @@ __device__ inline void list_push(uint32_t* counter, uint32_t* list, uint32_t idx
 //
 //   idx   : nullptr for round 0 (op i = thread i), else the deferred op list
 //   cellp : unused here (set duplicates are resolved after the rounds, k_set_locate)
+// The per-op body: returns the op's result (new value for writers); *deferred is set when a
+// structure change must happen first.
+template <int OP>
+__device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
+                                     uint32_t Y, uint32_t V, bool* deferred) {
+  uint32_t result = 0;
+  uint4 s;
+  DirSlot* d = dir_find(dir, dmask, X, &s);
+  if (!d || s.z == 0) {
+    *deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
+    return 0;
+  }
+  const uint32_t lg = meta_lg(s.x);
+  const uint32_t mask = (1u << lg) - 1u;
+  uint64_t* cells = row_cells(arena, s.z);
+  uint32_t pos = Y & mask;
+  if (OP == OP_GET) {
+    // src/smatrix.c:369-377 then :299: hit iff the probed slot's key == y
+    for (uint32_t step = 0; step <= mask; step++) {
+      uint64_t c = cells[pos];
+      if (cell_key(c) == Y) { result = cell_val(c); break; }
+      if (c == 0) break;
+      pos = (pos + 1) & mask;
+    }
+  } else if (Y != 0) {
+    uint64_t c = cells[pos];
+    for (uint32_t steps = 0;;) {
+      if (cell_key(c) == Y) break;                       // found
+      if (c == 0) {
+        // insert: reserve a place in `used` first; the reference inserts only
+        // while used <= size/2 (src/smatrix.c:346), otherwise it grows first
+        // (the snapshot taken with the directory slot spares a row that already stands at the
+        // threshold two contended atomics per op; a stale/low snapshot only costs the atomics)
+        if (s.w > (mask + 1u) / 2u) { *deferred = true; return 0; }
+        uint32_t u = atomicAdd(&d->used, 1u);
+        if (u > (mask + 1u) / 2u) {
+          atomicSub(&d->used, 1u);
+          *deferred = true;
+          return 0;
+        }
+        uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull,
+                                  (unsigned long long)pack_cell(Y, 0));
+        if (prev == 0) break;                            // claimed {y,0} (:354-356)
+        atomicSub(&d->used, 1u);                         // lost the slot: give back
+        c = prev;
+        continue;                                        // re-examine what is there now
+      }
+      if (++steps > mask) { *deferred = true; return 0; }  // no empty cell at all: let prep grow it
+      pos = (pos + 1) & mask;
+      c = cells[pos];
+    }
+    uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
+    if (OP == OP_INCR) result = atomicAdd(vp, V) + V;      // :241, wraps mod 2^32
+    else if (OP == OP_DECR) result = atomicSub(vp, V) - V; // :252
+    else { result = V; atomicExch(vp, V); }                // :230 (duplicates: see k_set_locate)
+  } else {
+    // y == 0 (quirk Q1, src/smatrix.c:297-303,:370-374): the first slot whose KEY
+    // field is 0 -- the row's own (0,v) entry or the first empty slot -- is a hit;
+    // nothing is inserted and `used` is not touched.  Done with a 64-bit CAS so
+    // that a concurrent claim of that empty slot by another key cannot be hit.
+    uint64_t c = ld_relaxed(&cells[pos]);
+    for (uint32_t guard = 0; guard < 4u * (mask + 1u); guard++) {
+      if (cell_key(c) == 0) {
+        uint32_t nv = OP == OP_INCR ? cell_val(c) + V : OP == OP_DECR ? cell_val(c) - V : V;
+        uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]),
+                                  (unsigned long long)c, (unsigned long long)pack_cell(0, nv));
+        if (prev == c) { result = nv; break; }
+        c = prev;
+        continue;
+      }
+      pos = (pos + 1) & mask;
+      c = ld_relaxed(&cells[pos]);
+    }
+  }
+  return result;
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void k_apply(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
-    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer,
-    uint64_t* cellp) {
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = t < n;
-  uint32_t j = 0, X = 0, Y = 0, V = 0;
+  uint32_t j = 0;
+  bool deferred = false;
   if (live) {
     j = idx ? idx[t] : t;
-    X = xs[j];
-    Y = ys[j];
-    if (OP != OP_GET) V = vs[j];
-  }
-  bool deferred = false;
-  uint32_t result = 0;
-
-  if (live) {
-    uint4 s;
-    DirSlot* d = dir_find(dir, dmask, X, &s);
-    if (!d || s.z == 0) {
-      deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
-    } else {
-      const uint32_t lg = meta_lg(s.x);
-      const uint32_t mask = (1u << lg) - 1u;
-      uint64_t* cells = row_cells(arena, s.z);
-      uint32_t pos = Y & mask;
-      if (OP == OP_GET) {
-        // src/smatrix.c:369-377 then :299: hit iff the probed slot's key == y
-        for (uint32_t step = 0; step <= mask; step++) {
-          uint64_t c = cells[pos];
-          if (cell_key(c) == Y) { result = cell_val(c); break; }
-          if (c == 0) break;
-          pos = (pos + 1) & mask;
-        }
-      } else if (Y != 0) {
-        uint64_t c = cells[pos];
-        for (uint32_t steps = 0;;) {
-          if (cell_key(c) == Y) break;                       // found
-          if (c == 0) {
-            // insert: reserve a place in `used` first; the reference inserts only
-            // while used <= size/2 (src/smatrix.c:346), otherwise it grows first
-            uint32_t u = atomicAdd(&d->used, 1u);
-            if (u > (mask + 1u) / 2u) {
-              atomicSub(&d->used, 1u);
-              deferred = true;
-              break;
-            }
-            uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull,
-                                      (unsigned long long)pack_cell(Y, 0));
-            if (prev == 0) break;                            // claimed {y,0} (:354-356)
-            atomicSub(&d->used, 1u);                         // lost the slot: give back
-            c = prev;
-            continue;                                        // re-examine what is there now
-          }
-          if (++steps > mask) { deferred = true; break; }    // no empty cell at all: let prep grow it
-          pos = (pos + 1) & mask;
-          c = cells[pos];
-        }
-        if (!deferred) {
-          uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
-          if (OP == OP_INCR) result = atomicAdd(vp, V) + V;      // :241, wraps mod 2^32
-          else if (OP == OP_DECR) result = atomicSub(vp, V) - V; // :252
-          else { result = V; atomicExch(vp, V); }                  // :230 (duplicates: see k_set_locate)
-        }
-      } else {
-        // y == 0 (quirk Q1, src/smatrix.c:297-303,:370-374): the first slot whose KEY
-        // field is 0 -- the row's own (0,v) entry or the first empty slot -- is a hit;
-        // nothing is inserted and `used` is not touched.  Done with a 64-bit CAS so
-        // that a concurrent claim of that empty slot by another key cannot be hit.
-        uint64_t c = ld_relaxed(&cells[pos]);
-        for (uint32_t guard = 0; guard < 4u * (mask + 1u); guard++) {
-          if (cell_key(c) == 0) {
-            uint32_t nv = OP == OP_INCR ? cell_val(c) + V : OP == OP_DECR ? cell_val(c) - V : V;
-            uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]),
-                                      (unsigned long long)c, (unsigned long long)pack_cell(0, nv));
-            if (prev == c) { result = nv; break; }
-            c = prev;
-            continue;
-          }
-          pos = (pos + 1) & mask;
-          c = ld_relaxed(&cells[pos]);
-        }
-      }
-    }
-    if (!deferred) out[j] = result;
+    uint32_t r = apply_one<OP>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
+    if (!deferred) out[j] = r;
   }
   if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
+}
+
+// ---- op kernel with in-tile aggregation (incr / decr) -----------------------------
+//
+// Under Zipf(1.1) x Zipf(1.1) 1.5 % of all ops hit ONE cell and a few dozen cells take a
+// quarter of the stream; their atomics serialise at the memory side (~34 ns each, measured:
+// profiles/r01_*), which alone set the un-aggregated kernel's time.  Here a workgroup first
+// folds its tile of AGG_TILE ops in an LDS hash table keyed by (x,y):
+//   phase 1  every op CAS-claims/joins its key's LDS slot and atomically adds its value to the
+//            slot's sum; the value the sum had before is the op's prefix inside the tile
+//   phase 2  one lane per DISTINCT key applies the tile's total with the per-op body above
+//            (directory lookup, probe, claim, ONE global atomic) and leaves the cell's old value
+//   phase 3  every op returns  old + prefix + v  (incr)  /  old - prefix - v  (decr)
+// -- the values a serial execution of the tile's ops in LDS-arrival order returns, i.e. a legal
+// serialisation.  Keys with y == 0 (quirk path) and the all-ones key take the per-op body.
+#ifndef SMX_AGG_OPT
+#define SMX_AGG_OPT 4
+#endif
+constexpr uint32_t AGG_OPT = SMX_AGG_OPT;          // ops per lane
+constexpr uint32_t AGG_TILE = 256 * AGG_OPT;       // ops per workgroup
+constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/2)
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_apply_agg(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
+  static_assert(OP == OP_INCR || OP == OP_DECR, "aggregation is for commutative ops");
+  __shared__ uint64_t l_key[AGG_SLOTS];     // (x | y<<32); after phase 2 the low word = status
+  __shared__ uint32_t l_sum[AGG_SLOTS];     // running sum; after phase 2 the cell's old value
+  __shared__ uint16_t l_list[AGG_TILE];     // occupied slots, compact
+  __shared__ uint32_t l_n;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < AGG_SLOTS; i += 256) { l_key[i] = ~0ull; l_sum[i] = 0; }
+  if (tid == 0) l_n = 0;
+  __syncthreads();
+
+  const uint32_t tile0 = blockIdx.x * AGG_TILE;
+  uint32_t j[AGG_OPT], V[AGG_OPT], pre[AGG_OPT], slot[AGG_OPT];
+  // phase 1
+#pragma unroll
+  for (uint32_t k = 0; k < AGG_OPT; k++) {
+    const uint32_t t = tile0 + k * 256 + tid;
+    slot[k] = ~0u;                 // ~0: no op; ~0-1: per-op path
+    if (t >= n) continue;
+    j[k] = idx ? idx[t] : t;
+    const uint32_t X = xs[j[k]], Y = ys[j[k]];
+    V[k] = vs[j[k]];
+    const uint64_t key = (uint64_t)X | ((uint64_t)Y << 32);
+    if (Y == 0 || key == ~0ull) { slot[k] = ~0u - 1; continue; }
+    uint32_t h = (X * 0x9E3779B1u) ^ (Y * 0x85EBCA77u);
+    h = (h ^ (h >> 15)) & (AGG_SLOTS - 1);
+    for (;;) {
+      uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&l_key[h]), ~0ull,
+                                (unsigned long long)key);
+      if (prev == ~0ull) l_list[atomicAdd(&l_n, 1u)] = (uint16_t)h;     // first of its key
+      if (prev == ~0ull || prev == key) break;
+      h = (h + 1) & (AGG_SLOTS - 1);
+    }
+    pre[k] = atomicAdd(&l_sum[h], V[k]);
+    slot[k] = h;
+  }
+  __syncthreads();
+  // phase 2
+  const uint32_t nd = l_n;
+  for (uint32_t i = tid; i < nd; i += 256) {
+    const uint32_t h = l_list[i];
+    const uint64_t key = l_key[h];
+    const uint32_t total = l_sum[h];
+    bool deferred = false;
+#if defined(SMX_ABLATE) && SMX_ABLATE == 1       /* timing ablation: no global work in phase 2 */
+    uint32_t res = total;
+#elif defined(SMX_ABLATE) && SMX_ABLATE == 2     /* timing ablation: lookup only, no atomic */
+    uint32_t res = apply_one<OP_GET>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), total, &deferred);
+#else
+    uint32_t res = apply_one<OP>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), total, &deferred);
+#endif
+    l_sum[h] = OP == OP_INCR ? res - total : res + total;    // the cell's value before the tile
+    reinterpret_cast<uint32_t*>(&l_key[h])[0] = deferred ? 1u : 0u;
+  }
+  __syncthreads();
+  // phase 3
+  uint32_t dmask_k = 0;          // which of this lane's ops are deferred
+#pragma unroll
+  for (uint32_t k = 0; k < AGG_OPT; k++) {
+    bool deferred = false;
+    if (slot[k] == ~0u - 1) {
+      uint32_t r = apply_one<OP>(dir, dmask, arena, xs[j[k]], ys[j[k]], V[k], &deferred);
+      if (!deferred) out[j[k]] = r;
+    } else if (slot[k] != ~0u) {
+      deferred = reinterpret_cast<uint32_t*>(&l_key[slot[k]])[0] != 0;
+      if (!deferred) {
+        const uint32_t old = l_sum[slot[k]];
+        out[j[k]] = OP == OP_INCR ? old + pre[k] + V[k] : old - pre[k] - V[k];
+      }
+    }
+    if (deferred) dmask_k |= 1u << k;
+  }
+  // deferred ops: ONE global atomic per workgroup (a per-wave atomic on the single list
+  // counter was the kernel's critical path when a few % of the ops defer)
+  __syncthreads();                       // everybody is done with l_sum / l_n
+  if (tid == 0) l_n = 0;
+  __syncthreads();
+  uint32_t mine = __popc(dmask_k), at = 0;
+  if (mine) at = atomicAdd(&l_n, mine);
+  __syncthreads();
+  if (tid == 0 && l_n) l_sum[0] = atomicAdd(&ctl->n_defer, l_n);
+  __syncthreads();
+  if (mine) {
+    at += l_sum[0];
+#pragma unroll
+    for (uint32_t k = 0; k < AGG_OPT; k++)
+      if (dmask_k & (1u << k)) defer[at++] = j[k];
+  }
 }
 
 // ---- prep kernel --------------------------------------------------------------
@@ -236,6 +353,11 @@ __global__ __launch_bounds__(256) void k_prep(
       uint64_t mx = ld_relaxed(w);
       if (mx == 0) {
         // create the row: reserve a directory place, then claim {meta,x} in one CAS
+        // (cheap pre-check: once the directory stands at its limit nobody touches the counter)
+        if (__hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= dir_limit) {
+          ctl->dir_full = 1;
+          break;
+        }
         uint32_t r = atomicAdd(&ctl->dir_used, 1u);
         if (r >= dir_limit) {
           atomicSub(&ctl->dir_used, 1u);
@@ -271,7 +393,7 @@ __global__ __launch_bounds__(256) void k_prep(
             pos = (pos + 1) & mask;
           }
           uint32_t used = __hip_atomic_load(&dir[h].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (absent && used > (mask + 1u) / 2u) {
+          if (absent && used > (mask + 1u) / 2u && !(meta & META_GROW)) {
             uint32_t old = atomicOr(&dir[h].meta, META_GROW);
             if (!(old & META_GROW)) {
               uint32_t k = atomicAdd(&ctl->n_tasks, 1u);

@@ -187,6 +187,7 @@ struct Matrix {
   uint32_t* h_small = nullptr;          // pinned
 
   smatrix_stats_t st = {};
+  uint32_t agg_min = 1024;              // batches at least this long fold duplicates in LDS first
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -241,7 +242,15 @@ template <int OP>
 void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                   const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
   hipLaunchKernelGGL((k_apply<OP>), dim3(blocks_for(n)), dim3(256), 0, s, m->d_ctl, m->d_dir,
-                     m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->cellp.p);
+                     m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  HIP_OK(hipGetLastError());
+}
+
+template <int OP>
+void launch_apply_agg(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
+                      const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
+  hipLaunchKernelGGL((k_apply_agg<OP>), dim3(blocks_for(n, AGG_TILE)), dim3(256), 0, s, m->d_ctl,
+                     m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   HIP_OK(hipGetLastError());
 }
 
@@ -253,8 +262,14 @@ void launch_apply_op(Matrix* m, int op, hipStream_t s, uint32_t n, const uint32_
   switch (op) {
     case OP_GET:  launch_apply<OP_GET>(m, s, n, idx, x, y, v, out, defer); break;
     case OP_SET:  launch_apply<OP_SET>(m, s, n, idx, x, y, v, out, defer); break;
-    case OP_INCR: launch_apply<OP_INCR>(m, s, n, idx, x, y, v, out, defer); break;
-    case OP_DECR: launch_apply<OP_DECR>(m, s, n, idx, x, y, v, out, defer); break;
+    case OP_INCR:
+      if (n >= m->agg_min) launch_apply_agg<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
+      else launch_apply<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
+      break;
+    case OP_DECR:
+      if (n >= m->agg_min) launch_apply_agg<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
+      else launch_apply<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
+      break;
     default: smx_die("bad op code");
   }
   if (timed) HIP_OK(hipEventRecord(m->ev1, s));
@@ -413,6 +428,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipMemsetAsync(m->d_dir, 0, (size_t)m->dir_size * sizeof(DirSlot), m->stream));
   m->arena.init(dev, 4u << 20, m->stream);
   HIP_OK(hipStreamSynchronize(m->stream));
+  if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   const char* prof = getenv("SMATRIX_PROFILE");
   m->profile = prof && *prof == '1';
 
