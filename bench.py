@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--batch-lg", type=int, default=BATCH_LG)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-lg", type=int, default=23)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="route through ShardedMatrix even with one rank (exercises the exchange path)")
     args = ap.parse_args()
 
     import torch
@@ -77,8 +79,11 @@ def main():
             sys.exit("launch with python -m torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:          # single process, --force-sharded
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
@@ -96,14 +101,14 @@ def main():
         gen.fill_device(s * B, B, xs[s].data_ptr(), ys[s].data_ptr(), stream)
     torch.cuda.synchronize()
 
-    if world > 1:
+    if sharded:
         from libsmatrix_amd.sharded import ShardedMatrix
         m = ShardedMatrix()
     else:
         m = SparseMatrix()
 
     def step(s):
-        if world > 1:
+        if sharded:
             m.apply_dev(OP_INCR, xs[s], ys[s], ones, out_i)
             m.apply_dev(OP_GET, xs[s], ys[s], None, out_g)
         else:
@@ -112,13 +117,13 @@ def main():
             m.apply_batch_dev(OP_GET, B, xs[s].data_ptr(), ys[s].data_ptr(), None, out_g.data_ptr(), stream)
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
         step(s)
-    local_m = m.local if world > 1 else m
+    local_m = m.local if sharded else m
     local_m.profile(True)          # HIP events around the op kernels, on the stream they run on
     fence()
     t0 = time.perf_counter()
@@ -128,7 +133,7 @@ def main():
     dt = time.perf_counter() - t0
     st = local_m.stats()
     local_m.profile(False)
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -146,7 +151,7 @@ def main():
                                "batches of 2^%d ops, step = incr batch + get batch on the same keys; "
                                "table grows from %d to %d batches of the 4e8-op stream during the timed steps"
                                % (args.batch_lg, args.warmup, total_steps),
-                   "batch_ops": B, "parallelism": "row-hash shards x%d" % world if world > 1 else "single GPU"},
+                   "batch_ops": B, "parallelism": "row-hash shards x%d" % world if sharded else "single GPU"},
         "sanity_all_gets_positive": ok,
     }
     if rank == 0:
@@ -171,7 +176,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_sample_lg)
         print(json.dumps(res))
     m.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

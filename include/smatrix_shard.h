@@ -1,0 +1,38 @@
+/*
+ * smatrix_shard.h -- device-side helpers for the row-hash sharded (multi-GPU) path.
+ *
+ * No reference counterpart: the reference is one process.  Rows are
+ * independent (there is no cross-row operation in src/smatrix.h:87-94), so a node's GPUs
+ * each own the rows with smatrix_shard_of(x, nshards) == rank; ops are routed to the owner
+ * with one all-to-all and results come back with a second one (libsmatrix_amd/sharded.py).
+ * These entry points do the on-GPU part: partition a batch by owner and un-permute results.
+ * All pointers named d_* are device memory; hip_stream is a hipStream_t passed as void*.
+ */
+#ifndef SMATRIX_SHARD_H
+#define SMATRIX_SHARD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* owner shard of row x: floor(mix(x) * nshards / 2^32), nshards <= 64 */
+uint32_t smatrix_shard_of(uint32_t x, uint32_t nshards);
+
+/* Reorders the n ops shard by shard.  counts_host[s] (host) = ops owned by shard s;
+ * d_perm[i] = position of op i in the reordered arrays d_xo/d_yo/d_vo (d_v, d_vo may be NULL);
+ * d_work: >= 512 bytes of device scratch.  Synchronises hip_stream.  Returns 0 on success. */
+int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
+                          uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
+                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream);
+
+/* d_out[i] = d_src[d_perm[i]] : routes results back into op order */
+int smatrix_gather_dev(size_t n, const uint32_t* d_src, const uint32_t* d_perm, uint32_t* d_out,
+                       void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

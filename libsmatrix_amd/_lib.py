@@ -66,6 +66,10 @@ def load():
         "smatrix_row_info": (C.c_int, [H, C.c_uint32, u32p, u32p]),
         "smatrix_row_slots": (C.c_uint32, [H, C.c_uint32, u32p, C.c_uint32]),
         "smatrix_device_available": (C.c_int, []),
+        # include/smatrix_shard.h
+        "smatrix_shard_of": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+        "smatrix_partition_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V, V, V]),
+        "smatrix_gather_dev": (C.c_int, [C.c_size_t, V, V, V, V]),
         # include/smx_stream.h
         "smx_stream_new": (V, [C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_int]),
         "smx_stream_free": (None, [V]),

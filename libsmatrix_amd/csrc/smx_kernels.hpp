@@ -698,6 +698,80 @@ __global__ void k_row_info(DirSlot* dir, uint32_t dmask, uint32_t x, uint32_t* o
   out4[3] = d ? s.z : 0;
 }
 
+// ---- row-hash sharding over the GPUs of a node (include/smatrix_shard.h) --------------------
+// owner(x) = floor(fmix32(x ^ salt) * nshards / 2^32): the HIGH bits of a differently salted mix,
+// so that the rows of one shard still spread over all low-bit buckets of its local directory.
+__host__ __device__ inline uint32_t shard_mix(uint32_t h) {
+  h ^= 0x9E3779B9u;
+  h ^= h >> 16; h *= 0x85ebca6bU; h ^= h >> 13; h *= 0xc2b2ae35U; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline uint32_t shard_of(uint32_t x, uint32_t nshards) {
+  return (uint32_t)(((uint64_t)shard_mix(x) * nshards) >> 32);
+}
+
+constexpr uint32_t MAX_SHARDS = 64;
+
+// pass 1: per-shard op counts (LDS histogram per workgroup, one global atomic per shard per WG)
+__global__ __launch_bounds__(256) void k_part_count(uint32_t n, const uint32_t* __restrict__ xs,
+                                                    uint32_t nshards, unsigned long long* counts) {
+  __shared__ uint32_t h[MAX_SHARDS];
+  if (threadIdx.x < MAX_SHARDS) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    atomicAdd(&h[shard_of(xs[i], nshards)], 1u);
+  __syncthreads();
+  if (threadIdx.x < nshards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// pass 2: scatter into shard-contiguous order.  cursors[] start at the exclusive offsets; a
+// workgroup reserves its range per shard with one global atomic, lanes rank inside it in LDS.
+// perm[i] = position of op i in the partitioned arrays (used to route results back).
+constexpr uint32_t PART_OPT = 8;
+__global__ __launch_bounds__(256) void k_part_scatter(
+    uint32_t n, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t nshards, unsigned long long* cursors,
+    uint32_t* __restrict__ perm, uint32_t* __restrict__ xo, uint32_t* __restrict__ yo,
+    uint32_t* __restrict__ vo) {
+  __shared__ uint32_t cnt[MAX_SHARDS];
+  __shared__ unsigned long long base[MAX_SHARDS];
+  if (threadIdx.x < MAX_SHARDS) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * 256 * PART_OPT;
+  uint32_t sh[PART_OPT], rk[PART_OPT], X[PART_OPT];
+#pragma unroll
+  for (uint32_t k = 0; k < PART_OPT; k++) {
+    uint32_t i = tile0 + k * 256 + threadIdx.x;
+    sh[k] = ~0u;
+    if (i < n) {
+      X[k] = xs[i];
+      sh[k] = shard_of(X[k], nshards);
+      rk[k] = atomicAdd(&cnt[sh[k]], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nshards && cnt[threadIdx.x])
+    base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < PART_OPT; k++) {
+    uint32_t i = tile0 + k * 256 + threadIdx.x;
+    if (sh[k] == ~0u) continue;
+    uint32_t dst = (uint32_t)(base[sh[k]] + rk[k]);
+    perm[i] = dst;
+    xo[dst] = X[k];
+    yo[dst] = ys[i];
+    if (vs) vo[dst] = vs[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather(uint32_t n, const uint32_t* __restrict__ src,
+                                                const uint32_t* __restrict__ perm,
+                                                uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[perm[i]];
+}
+
 // ---- stream generator (include/smx_stream.h) -----------------------------------------
 __device__ inline uint64_t splitmix_at(uint64_t seed, uint64_t j) {
   uint64_t z = seed + (j + 1) * 0x9e3779b97f4a7c15ULL;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/smatrix_batch.h"
+#include "../../include/smatrix_shard.h"
 #include "smx_stream_priv.h"
 
 using namespace smx;
@@ -687,6 +688,44 @@ uint32_t smatrix_row_slots(smatrix_t* self, uint32_t x, uint32_t* kv, uint32_t c
   uint32_t n = std::min(f[1], cap_slots);
   HIP_OK(hipMemcpy(kv, m->arena.base + (uint64_t)f[3] * UNIT_BYTES, (size_t)n * 8, hipMemcpyDeviceToHost));
   return f[1];
+}
+
+// ---- sharding helpers (include/smatrix_shard.h) ------------------------------------------------
+uint32_t smatrix_shard_of(uint32_t x, uint32_t nshards) { return shard_of(x, nshards); }
+
+int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
+                          uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
+                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream) {
+  if (nshards == 0 || nshards > MAX_SHARDS || n >= (1ull << 32)) return -1;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  unsigned long long* work = static_cast<unsigned long long*>(d_work);   // >= 64 * 8 bytes
+  HIP_OK(hipMemsetAsync(work, 0, MAX_SHARDS * sizeof(unsigned long long), s));
+  if (n) {
+    hipLaunchKernelGGL(k_part_count, dim3(std::min<uint32_t>(blocks_for(n), 2048)), dim3(256), 0, s,
+                       (uint32_t)n, d_x, nshards, work);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipMemcpyAsync(counts_host, work, nshards * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  unsigned long long cur[MAX_SHARDS] = {0}, run = 0;
+  for (uint32_t i = 0; i < nshards; i++) { cur[i] = run; run += counts_host[i]; }
+  HIP_OK(hipMemcpyAsync(work, cur, nshards * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+  if (n) {
+    hipLaunchKernelGGL(k_part_scatter, dim3(blocks_for(n, 256 * PART_OPT)), dim3(256), 0, s, (uint32_t)n,
+                       d_x, d_y, d_v, nshards, work, d_perm, d_xo, d_yo, d_vo);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipStreamSynchronize(s));   // `cur` lives on this stack frame
+  return 0;
+}
+
+int smatrix_gather_dev(size_t n, const uint32_t* d_src, const uint32_t* d_perm, uint32_t* d_out,
+                       void* hip_stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     (uint32_t)n, d_src, d_perm, d_out);
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 // ---- stream generator, device side (include/smx_stream.h) -------------------------------

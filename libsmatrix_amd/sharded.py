@@ -1,0 +1,121 @@
+"""ShardedMatrix -- one matrix row-hash-sharded over the GPUs of a node.
+
+No reference counterpart (the reference is a single process).  The path
+shards naturally: rows are independent, so rank r owns the rows with
+``smatrix_shard_of(x, world) == r`` (include/smatrix_shard.h) and keeps them in its own
+HBM-resident SparseMatrix.  A batch submitted on any rank is
+
+  1. partitioned by owner on the GPU (k_part_count / k_part_scatter),
+  2. routed with ``all_to_all_single`` (RCCL over xGMI; gloo in the CPU tests),
+  3. applied by each owner's local op kernels,
+  4. its results routed back with a second ``all_to_all_single`` and un-permuted.
+
+One process per GPU, ``torch.distributed`` for the exchange; torch is plumbing here
+(device buffers + the collective), the compute is the HIP library.
+
+The two device-side pieces are injectable so that the routing logic can be exercised on
+CPU with gloo (tests/test_sharded_gloo.py supplies a CPU partitioner and an oracle-backed
+shard); the defaults are the HIP implementations and fail loudly without a GPU.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .matrix import OP_GET, SparseMatrix
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipShard:
+    """The local shard: a SparseMatrix driven with device pointers on torch's current stream."""
+
+    def __init__(self, filename=None):
+        self.m = SparseMatrix(filename)
+
+    def apply(self, op, x, y, v, out):
+        n = x.numel()
+        if n:
+            self.m.apply_batch_dev(op, n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None,
+                                   out.data_ptr(), _stream())
+
+    def close(self):
+        self.m.close()
+
+
+class HipPartitioner:
+    """partition-by-owner and result gather on the GPU (include/smatrix_shard.h)."""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.work = torch.zeros(128, dtype=torch.int64, device=device)
+
+    def partition(self, x, y, v, world):
+        n = x.numel()
+        counts = (C.c_uint64 * world)()
+        perm = torch.empty(n, dtype=torch.int32, device=x.device)
+        xo, yo = torch.empty_like(x), torch.empty_like(y)
+        vo = torch.empty_like(v) if v is not None else None
+        rc = self.lib.smatrix_partition_dev(
+            n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None, world,
+            C.cast(counts, _lib.u64p), self.work.data_ptr(), perm.data_ptr(), xo.data_ptr(), yo.data_ptr(),
+            vo.data_ptr() if vo is not None else None, _stream())
+        if rc:
+            raise RuntimeError("smatrix_partition_dev failed")
+        return [int(c) for c in counts], perm, xo, yo, vo
+
+    def gather(self, src, perm, out):
+        self.lib.smatrix_gather_dev(out.numel(), src.data_ptr(), perm.data_ptr(), out.data_ptr(), _stream())
+
+
+class ShardedMatrix:
+    def __init__(self, group=None, shard=None, partitioner=None, device=None):
+        if not dist.is_initialized():
+            raise RuntimeError("ShardedMatrix needs an initialised torch.distributed process group")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if shard is None or partitioner is None:
+            device = device or torch.device("cuda", torch.cuda.current_device())
+        self.shard = shard if shard is not None else HipShard()
+        self.part = partitioner if partitioner is not None else HipPartitioner(device)
+        self.exchanged_ops = 0
+
+    @property
+    def local(self):
+        """the rank's own SparseMatrix (stats / profiling)"""
+        return self.shard.m
+
+    def owner(self, x):
+        return _lib.load().smatrix_shard_of(int(x), self.world)
+
+    def apply_dev(self, op, x, y, v, out):
+        """x, y, v, out: 1-D int32 tensors on this rank's device (v None for get).
+        COLLECTIVE: every rank must call it with the same op (batch sizes may differ)."""
+        counts, perm, xo, yo, vo = self.part.partition(x, y, None if op == OP_GET else v, self.world)
+        send = torch.tensor(counts, dtype=torch.int64, device=x.device)
+        recv = torch.empty(self.world, dtype=torch.int64, device=x.device)
+        dist.all_to_all_single(recv, send, group=self.group)
+        rcounts = [int(c) for c in recv.tolist()]
+        nr = sum(rcounts)
+        xr = torch.empty(nr, dtype=x.dtype, device=x.device)
+        yr = torch.empty(nr, dtype=x.dtype, device=x.device)
+        dist.all_to_all_single(xr, xo, rcounts, counts, group=self.group)
+        dist.all_to_all_single(yr, yo, rcounts, counts, group=self.group)
+        vr = None
+        if op != OP_GET:
+            vr = torch.empty(nr, dtype=x.dtype, device=x.device)
+            dist.all_to_all_single(vr, vo, rcounts, counts, group=self.group)
+        outr = torch.empty(nr, dtype=x.dtype, device=x.device)
+        self.shard.apply(op, xr, yr, vr, outr)
+        back = torch.empty(x.numel(), dtype=x.dtype, device=x.device)
+        dist.all_to_all_single(back, outr, counts, rcounts, group=self.group)
+        self.part.gather(back, perm, out)
+        self.exchanged_ops += nr
+        return out
+
+    def close(self):
+        self.shard.close()

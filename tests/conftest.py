@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime (same soname as /opt/rocm's).  Whichever is loaded first
+# serves the whole process, and torch only finds its GPUs when its own copy won -- so tests that
+# use both import torch BEFORE the HIP library is dlopen()ed (bench.py does the same).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,110 @@
+"""Worker for tests/test_sharded_gloo.py: run under torch.distributed.run with the gloo backend.
+The routing logic under test is libsmatrix_amd/sharded.py; the two device-side pieces are
+replaced by CPU stand-ins (a numpy partitioner and an ORACLE-backed shard -- checker code,
+which is why they live under tests/)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from libsmatrix_amd import _lib, Stream  # noqa: E402
+from libsmatrix_amd.sharded import ShardedMatrix  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def shard_of_np(x, world):
+    """numpy restatement of shard_of() in smx_kernels.hpp (cross-checked against the library)"""
+    h = x.astype(np.uint32) ^ np.uint32(0x9E3779B9)
+    h ^= h >> np.uint32(16); h = (h * np.uint32(0x85EBCA6B)).astype(np.uint32)
+    h ^= h >> np.uint32(13); h = (h * np.uint32(0xC2B2AE35)).astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    return ((h.astype(np.uint64) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+
+
+class NumpyPartitioner:
+    def partition(self, x, y, v, world):
+        xn = x.numpy().view(np.uint32)
+        own = shard_of_np(xn, world)
+        order = np.argsort(own, kind="stable")
+        perm = np.empty_like(order); perm[order] = np.arange(order.size)
+        counts = np.bincount(own, minlength=world).tolist()
+        o = torch.from_numpy(order)
+        return counts, torch.from_numpy(perm.astype(np.int32)), x[o], y[o], (v[o] if v is not None else None)
+
+    def gather(self, src, perm, out):
+        out.copy_(src[perm.long()])
+
+
+class OracleShard:
+    def __init__(self):
+        self.m = O.Oracle()
+
+    def apply(self, op, x, y, v, out):
+        r = self.m.apply(op, x.numpy().view(np.uint32), y.numpy().view(np.uint32),
+                         v.numpy().view(np.uint32) if v is not None else None)
+        out.copy_(torch.from_numpy(r.view(np.int32)))
+
+    def close(self):
+        self.m.close()
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _lib.load()
+    probe = np.array([0, 1, 2, 12345, 0xFFFFFFFF, 0x80000000, 777777], dtype=np.uint32)
+    assert [lib.smatrix_shard_of(int(p), world) for p in probe] == shard_of_np(probe, world).tolist()
+
+    sm = ShardedMatrix(shard=OracleShard(), partitioner=NumpyPartitioner())
+    n = 30000 + 1000 * rank                          # ragged batch sizes
+    gen = Stream("zipf", 12345 + rank, 50000, 1.1, 1)
+    x, y = gen.fill(0, n)
+    xt, yt = torch.from_numpy(x.view(np.int32)), torch.from_numpy(y.view(np.int32))
+    ones = torch.ones(n, dtype=torch.int32)
+    out_i = torch.empty(n, dtype=torch.int32); out_g = torch.empty(n, dtype=torch.int32)
+    sm.apply_dev(2, xt, yt, ones, out_i)
+    sm.apply_dev(0, xt, yt, None, out_g)
+    # an empty batch on one rank must not hang the collective
+    e = torch.empty(0, dtype=torch.int32)
+    sm.apply_dev(0, e if rank == 0 else xt[:10], e if rank == 0 else yt[:10], None,
+                 torch.empty(0 if rank == 0 else 10, dtype=torch.int32))
+
+    # expected: one oracle over the ops of ALL ranks
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n]))
+    mx = max(int(s) for s in sizes)
+    pad = torch.zeros((2, mx), dtype=torch.int32); pad[0, :n] = xt; pad[1, :n] = yt
+    allp = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(allp, pad)
+    ref = O.Oracle()
+    for r in range(world):
+        k = int(sizes[r])
+        ref.apply(O.OP_INCR, allp[r][0, :k].numpy().view(np.uint32), allp[r][1, :k].numpy().view(np.uint32),
+                  np.ones(k, np.uint32))
+    want = ref.apply(O.OP_GET, x, y)
+    assert (out_g.numpy().view(np.uint32) == want).all(), "sharded get != single-matrix oracle"
+    # incr returns: a legal serialisation => per key, the largest return over all ranks == final value
+    key = x.astype(np.uint64) << 32 | y
+    uk, inv = np.unique(key, return_inverse=True)
+    mine = np.zeros(uk.size, np.uint32); np.maximum.at(mine, inv, out_i.numpy().view(np.uint32))
+    assert (mine <= ref.apply(O.OP_GET, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32))).all()
+    # every row lives on exactly its owner, with the same length as in the single matrix
+    rows = sm.shard.m.list_rows()
+    assert (shard_of_np(rows, world) == rank).all(), "a row landed on the wrong shard"
+    assert all(sm.shard.m.rowlen(int(r)) == ref.rowlen(int(r)) for r in rows[:500])
+    tot = torch.tensor([rows.size]); dist.all_reduce(tot)
+    assert int(tot) == ref.num_rows()
+    sm.close(); ref.close()
+    dist.barrier()
+    if rank == 0:
+        print("SHARDED_OK world=%d rows=%d" % (world, int(tot)))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

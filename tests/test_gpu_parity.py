@@ -328,3 +328,47 @@ def test_file_roundtrip_and_cross_open(G, oracle_mod, tmp_path, golden):
         w = W(p2)
         assert (w.apply(0, x, y) == want).all() and (w.apply(0, x, y + 40000) == want2).all()
         w.close()
+
+
+def test_sharded_path_one_rank_nccl():
+    """the HIP partitioner + RCCL all_to_all + local shard with world_size 1 (all a 1-GPU box allows):
+    bench.py --force-sharded must produce the same sane line as the direct path"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sharded", "--batch-lg", "18",
+                        "--steps", "3", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["sanity_all_gets_positive"] and res["value"] > 0 and res["table"]["rows"] > 0
+
+
+def test_partition_kernels(G):
+    """smatrix_partition_dev / smatrix_gather_dev: a permutation that groups ops by owner shard"""
+    import ctypes as C
+    import torch
+    from libsmatrix_amd import _lib
+    from libsmatrix_amd.sharded import HipPartitioner
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    for n, world in ((1, 2), (1000, 3), (300001, 8), (0, 4)):
+        x = torch.from_numpy(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.int32)).to(dev)
+        y = torch.arange(n, dtype=torch.int32, device=dev)
+        v = y * 3
+        part = HipPartitioner(dev)
+        counts, perm, xo, yo, vo = part.partition(x, y, v, world)
+        torch.cuda.synchronize()
+        assert sum(counts) == n
+        own = np.array([lib.smatrix_shard_of(int(a), world) for a in x.cpu().numpy().view(np.uint32)[:2000]])
+        p = perm.cpu().numpy()
+        assert sorted(p.tolist()) == list(range(n))                       # a permutation
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        for i in range(min(n, 2000)):                                     # op i sits in its owner's range
+            assert starts[own[i]] <= p[i] < starts[own[i] + 1]
+        assert (yo.cpu().numpy()[p] == y.cpu().numpy()).all() and (vo.cpu().numpy()[p] == v.cpu().numpy()).all()
+        assert (xo.cpu().numpy()[p] == x.cpu().numpy()).all()
+        out = torch.empty_like(y)
+        part.gather(yo, perm, out)
+        torch.cuda.synchronize()
+        assert (out == y).all()

@@ -1,0 +1,17 @@
+"""CPU, world_size 2, gloo: the multi-GPU routing path (partition -> all_to_all -> local apply ->
+all_to_all back -> un-permute) of libsmatrix_amd/sharded.py against a single-matrix oracle."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sharded_two_ranks_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "tests", "sharded_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "SHARDED_OK world=2" in p.stdout
