@@ -58,6 +58,31 @@ def cpu_baseline(sample_ops):
     }
 
 
+def random_access_roofline(torch, dev, gib=4, touches=1 << 27):
+    """R_rand of this chip, measured now (not a datasheet number): pseudo-random
+    8-byte touches over a table-sized buffer, one kernel per mode, torch events on the stream
+    the probe kernel is launched on."""
+    from libsmatrix_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(gib << 27, dtype=torch.int64, device=dev)       # gib GiB
+    sink = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"buffer_gib": gib, "touches": touches}
+    for mode, name in ((0, "read8"), (3, "chain2"), (1, "atomic_ret"), (2, "atomic_noret")):
+        best = None
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lib.smx_probe_random_dev(buf.data_ptr(), buf.numel() * 8, touches, mode, 99 + rep, sink.data_ptr(), stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        out[name + "_gtouch_per_s"] = touches / (best * 1e-3) / 1e9
+    del buf
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +187,7 @@ def main():
         ops_g = st["kernel_ops_get"] / max(st["kernel_launches_get"], 1)
         ach_i = ops_i * BYTES_INCR / (ki * 1e-3) / 1e9 if ki else 0.0
         ach_g = ops_g * BYTES_GET / (kg * 1e-3) / 1e9 if kg else 0.0
-        res["roofline"] = {"bound": "hbm", "kernel": "k_apply<INCR> (round 0)", "achieved": ach_i,
+        res["roofline"] = {"bound": "hbm", "kernel": "k_apply_agg<INCR> (round 0)", "achieved": ach_i,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_i / HBM_PEAK_GBS, "traffic": None,
                            "avg_launch_ms": ki, "ops_per_launch": ops_i, "bytes_per_op": BYTES_INCR,
                            "gops_per_s": ops_i / (ki * 1e-3) / 1e9 if ki else 0.0}
@@ -170,8 +195,31 @@ def main():
                                "unit": "GB/s", "frac": ach_g / HBM_PEAK_GBS, "traffic": None,
                                "avg_launch_ms": kg, "ops_per_launch": ops_g, "bytes_per_op": BYTES_GET,
                                "gops_per_s": ops_g / (kg * 1e-3) / 1e9 if kg else 0.0}
+        # HBM-side bytes per launch from the committed PMC passes of this same command (rocprofv3
+        # cannot be run from inside the measured process); null when the profile is absent
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if world == 1 and args.batch_lg == BATCH_LG:
+                res["roofline"]["traffic"] = pmc["k_apply_agg_incr"]["bytes_per_launch"]
+                res["roofline_get"]["traffic"] = pmc["k_apply_get"]["bytes_per_launch"]
+                res["roofline"]["traffic_source"] = res["roofline_get"]["traffic_source"] = "profiles/r01_pmc_summary.txt"
+        except Exception:
+            pass
         res["table"] = {k: st[k] for k in ("rows", "dir_slots", "arena_units", "arena_mapped", "batches",
                                            "rounds", "deferred_ops", "rows_grown", "dir_grown")}
+        if world == 1:
+            ra = random_access_roofline(torch, dev)
+            g_get = res["roofline_get"]["gops_per_s"]; g_inc = res["roofline"]["gops_per_s"]
+            ra.update({
+                "get_gops_per_s": g_get, "incr_gops_per_s": g_inc,
+                # a get is a directory touch + a dependent cell touch; an incr adds one returning atomic
+                "get_frac_of_chain2": g_get / ra["chain2_gtouch_per_s"],
+                "get_frac_of_read8": g_get / ra["read8_gtouch_per_s"],
+                "incr_frac_of_atomic_ret": g_inc / ra["atomic_ret_gtouch_per_s"],
+                "note": "ceilings are uniform-random over the buffer; the Zipf stream re-touches hot lines "
+                        "in L2/Infinity Cache, so fractions above 1 are cache assistance, not an error",
+            })
+            res["random_access"] = ra
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_sample_lg)
         print(json.dumps(res))

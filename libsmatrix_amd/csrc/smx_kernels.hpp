@@ -75,6 +75,13 @@ __device__ inline uint32_t fmix32(uint32_t h) {
   return h;
 }
 
+__device__ inline uint64_t splitmix_at(uint64_t seed, uint64_t j) {
+  uint64_t z = seed + (j + 1) * 0x9e3779b97f4a7c15ULL;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+
 __device__ inline uint64_t pack_cell(uint32_t key, uint32_t value) {
   return (uint64_t)key | ((uint64_t)value << 32);   // little-endian {key,value}
 }
@@ -772,14 +779,33 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t n, const uint32_t* __re
   if (i < n) out[i] = src[perm[i]];
 }
 
-// ---- stream generator (include/smx_stream.h) -----------------------------------------
-__device__ inline uint64_t splitmix_at(uint64_t seed, uint64_t j) {
-  uint64_t z = seed + (j + 1) * 0x9e3779b97f4a7c15ULL;
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-  return z ^ (z >> 31);
+// ---- random-access probes (include/smx_probe.h) ------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_probe_random(uint64_t* buf, uint64_t words, uint64_t touches,
+                                                      uint64_t seed, unsigned long long* sink) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t acc = 0;
+  for (uint64_t i = t; i < touches; i += 4 * stride) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t j = i + k * stride;
+      if (j >= touches) break;
+      const uint64_t w = splitmix_at(seed, j) % words;
+      if (MODE == 0) acc += buf[w];
+      else if (MODE == 1) acc += atomicAdd(reinterpret_cast<uint32_t*>(&buf[w]), 1u);
+      else if (MODE == 2) atomicAdd(reinterpret_cast<uint32_t*>(&buf[w]), 1u);
+      else {
+        const uint4 a = *reinterpret_cast<const uint4*>(&buf[w & ~1ull]);
+        const uint64_t w2 = (splitmix_at(seed ^ a.x, j) + a.y) % words;
+        acc += buf[w2];
+      }
+    }
+  }
+  if (MODE != 2 && acc == 0x1234567deadbeefULL) *sink = acc;   // keeps the loads alive
 }
 
+// ---- stream generator (include/smx_stream.h) -----------------------------------------
 __device__ inline uint32_t draw_id(int dist, uint32_t n_ids, const double* cdf, int scramble, uint64_t r) {
   uint32_t id;
   if (dist == 0) {

@@ -21,6 +21,7 @@
 
 #include "../../include/smatrix_batch.h"
 #include "../../include/smatrix_shard.h"
+#include "../../include/smx_probe.h"
 #include "smx_stream_priv.h"
 
 using namespace smx;
@@ -724,6 +725,26 @@ int smatrix_gather_dev(size_t n, const uint32_t* d_src, const uint32_t* d_perm, 
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_gather, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                      (uint32_t)n, d_src, d_perm, d_out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---- random-access probes (include/smx_probe.h) ------------------------------------------------
+int smx_probe_random_dev(void* d_buf, size_t bytes, size_t touches, int mode, uint64_t seed,
+                         void* d_sink, void* hip_stream) {
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  uint64_t* buf = static_cast<uint64_t*>(d_buf);
+  unsigned long long* sink = static_cast<unsigned long long*>(d_sink);
+  const uint64_t words = bytes / 8;
+  if (words < 2 || touches == 0) return -1;
+  const dim3 grid(256 * 8 * 4), block(256);     // 32 waves per CU on 256 CUs, grid-stride
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((k_probe_random<0>), grid, block, 0, s, buf, words, (uint64_t)touches, seed, sink); break;
+    case 1: hipLaunchKernelGGL((k_probe_random<1>), grid, block, 0, s, buf, words, (uint64_t)touches, seed, sink); break;
+    case 2: hipLaunchKernelGGL((k_probe_random<2>), grid, block, 0, s, buf, words, (uint64_t)touches, seed, sink); break;
+    case 3: hipLaunchKernelGGL((k_probe_random<3>), grid, block, 0, s, buf, words, (uint64_t)touches, seed, sink); break;
+    default: return -1;
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

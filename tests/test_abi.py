@@ -31,7 +31,7 @@ def exported(path):
 
 def test_every_declared_symbol_is_exported(built):
     syms = exported(os.path.join(built, "smatrix.so"))
-    for h in ("smatrix.h", "smatrix_batch.h", "smatrix_shard.h", "smx_stream.h"):
+    for h in ("smatrix.h", "smatrix_batch.h", "smatrix_shard.h", "smx_probe.h", "smx_stream.h"):
         names = declared(h)
         assert names, h
         missing = [n for n in names if n not in syms]
