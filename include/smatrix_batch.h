@@ -69,6 +69,7 @@ typedef struct {
   uint64_t deferred_ops;    /* ops re-run after a structure change */
   uint64_t rows_grown;      /* row doublings */
   uint64_t dir_grown;       /* directory rebuilds */
+  uint64_t rows_rebalanced; /* big rows whose insert quotas were re-partitioned */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];

@@ -181,6 +181,7 @@ struct Matrix {
 
   DevBuf<uint32_t> defer[2];
   DevBuf<GrowTask> tasks;
+  DevBuf<uint32_t> rebal;
   DevBuf<uint32_t> map_old, map_new;
   DevBuf<uint64_t> cellp;
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
@@ -306,7 +307,7 @@ void grow_rows(Matrix* m, hipStream_t s) {
   hipLaunchKernelGGL(k_grow_fixdup, dim3(std::min<uint32_t>(blocks_for(nt, 64), 1024)), dim3(64), 0, s,
                      m->d_ctl, m->tasks.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
-                     m->d_ctl, m->tasks.p, m->d_dir);
+                     m->d_ctl, m->tasks.p, m->d_dir, m->arena.base);
   HIP_OK(hipGetLastError());
   m->arena_next += gu;   // exact: plan hands out precisely grow_units
   m->st.rows_grown += nt;
@@ -319,6 +320,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   m->defer[0].need(n);
   m->defer[1].need(n);
   m->tasks.need(n);
+  m->rebal.need(n);
   if (op == OP_SET) m->cellp.need(n);
   m->st.batches++;
 
@@ -335,7 +337,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
-                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p);
+                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->rebal.p);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
@@ -345,6 +347,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (nd == 0) break;
     m->st.deferred_ops += nd;
     if (m->h_ctl->n_tasks) grow_rows(m, s);
+    if (m->h_ctl->n_rebal) {
+      hipLaunchKernelGGL(k_rebal, dim3(std::min<uint32_t>(blocks_for(m->h_ctl->n_rebal, 64), 1024)), dim3(64), 0, s,
+                         m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
+      HIP_OK(hipGetLastError());
+      m->st.rows_rebalanced += m->h_ctl->n_rebal;
+    }
     if (m->h_ctl->dir_full) grow_directory(m, 4, s);
     else if ((uint64_t)m->dir_used * 2 >= m->dir_size) grow_directory(m, 2, s);
     idx = dl;
@@ -462,7 +470,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->d_small) (void)hipFree(m->d_small);
       if (m->h_small) (void)hipHostFree(m->h_small);
       for (auto& d : m->defer) d.release();
-      m->tasks.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
+      m->tasks.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -530,7 +538,7 @@ int smatrix_rowlen_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x, uin
   std::lock_guard<std::mutex> g(m->mu);
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
   hipLaunchKernelGGL(k_rowlen, dim3(blocks_for(n)), dim3(256), 0, s, m->d_dir, m->dir_size - 1,
-                     (uint32_t)n, d_x, d_out);
+                     m->arena.base, (uint32_t)n, d_x, d_out);
   HIP_OK(hipGetLastError());
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -545,7 +553,7 @@ int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t*
   m->sx.need(n); m->so.need(n);
   HIP_OK(hipMemcpyAsync(m->sx.p, x, n * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_rowlen, dim3(blocks_for(n)), dim3(256), 0, s, m->d_dir, m->dir_size - 1,
-                     (uint32_t)n, m->sx.p, m->so.p);
+                     m->arena.base, (uint32_t)n, m->sx.p, m->so.p);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(out, m->so.p, n * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -660,7 +668,8 @@ void smatrix_profile(smatrix_t* self, int on) {
 
 static void row_info_locked(Matrix* m, uint32_t x, uint32_t* four) {
   hipStream_t s = m->stream;
-  hipLaunchKernelGGL(k_row_info, dim3(1), dim3(1), 0, s, m->d_dir, m->dir_size - 1, x, m->d_small + 4);
+  hipLaunchKernelGGL(k_row_info, dim3(1), dim3(1), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, x,
+                     m->d_small + 4);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(m->h_small + 4, m->d_small + 4, 16, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));

@@ -372,3 +372,41 @@ def test_partition_kernels(G):
         part.gather(yo, perm, out)
         torch.cuda.synchronize()
         assert (out == y).all()
+
+
+def test_big_rows_subcounters(G, oracle_mod, tmp_path):
+    """rows of >= 2^15 cells count inserts in per-row sub-counters with quotas:
+    rowlen/size must stay exactly the reference's across growth, reload and quota re-partitioning"""
+    rng = np.random.default_rng(21)
+    g, o = G(), oracle_mod.Oracle()
+    total = 0
+    for rnd in range(10):
+        n = 20000 + 7000 * rnd
+        x = rng.integers(0, 3, n, dtype=np.uint32)                 # three giant rows
+        y = rng.integers(1, 1 << 31, n, dtype=np.uint32)
+        v = np.ones(n, np.uint32)
+        g.apply(2, x, y, v); o.apply(2, x, y, v)
+        total += n
+        for r in range(3):
+            assert g.row_info(r) == o.row_info(r), (rnd, r)
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
+    assert g.stats()["rows_rebalanced"] >= 0
+    # land exactly on thresholds: one op at a time around the 2^15 -> 2^16 doubling of a fresh row
+    keys = np.arange(1, (1 << 15) + 40, dtype=np.uint32) * 7
+    g.apply(2, np.full(keys.size - 80, 9, np.uint32), keys[:-80], np.ones(keys.size - 80, np.uint32))
+    o.apply(2, np.full(keys.size - 80, 9, np.uint32), keys[:-80], np.ones(keys.size - 80, np.uint32))
+    for k in keys[-80:].tolist():
+        assert g.incr(9, k, 1) == o.incr(9, k, 1)
+        assert g.row_info(9) == o.row_info(9)
+    # reload a file holding big rows, keep inserting
+    path = str(tmp_path / "big.smx")
+    w = oracle_mod.Oracle(path)
+    yb = rng.integers(1, 1 << 31, 50000, dtype=np.uint32)
+    w.apply(2, np.zeros(50000, np.uint32), yb, np.ones(50000, np.uint32)); w.close()
+    m, o2 = G(path), oracle_mod.Oracle(path)
+    assert m.row_info(0) == o2.row_info(0)
+    y2 = rng.integers(1, 1 << 31, 60000, dtype=np.uint32)
+    m.apply(2, np.zeros(60000, np.uint32), y2, np.ones(60000, np.uint32))
+    o2.apply(2, np.zeros(60000, np.uint32), y2, np.ones(60000, np.uint32))
+    assert m.row_info(0) == o2.row_info(0) and (m.apply(0, np.zeros(60000, np.uint32), y2) == o2.apply(0, np.zeros(60000, np.uint32), y2)).all()
+    m.close(); o2.close(); g.close(); o.close()
