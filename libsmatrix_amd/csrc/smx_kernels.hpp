@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void k_prep(
             if (c == 0) break;
             pos = (pos + 1) & mask;
           }
+          if (absent) meta = __hip_atomic_load(&dir[h].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (absent && !(meta & (META_GROW | META_REBAL))) {
             uint32_t used = __hip_atomic_load(&dir[h].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lg >= BIG_LG) used += subs_sum(row_subs(arena, base, lg));
@@ -538,7 +539,14 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
     if (p < old_size) cur = row_cells(arena, k.old_base)[p];
     bool ne = cur != 0;
     uint64_t m = __ballot(ne);
-    if (lane == 0 && m) atomicAdd(&k.count, (uint32_t)__popcll(m));
+    if (lane == 0 && m) {
+      // a giant row is moved by thousands of waves: shard its count over the NEW block's
+      // (still unused) sub-counter lines instead of serialising on one word
+      if (k.old_lg + 1 >= BIG_LG)
+        atomicAdd(&row_subs(arena, k.new_base, k.old_lg + 1)[ch & (SUBS - 1u)].cnt, (uint32_t)__popcll(m));
+      else
+        atomicAdd(&k.count, (uint32_t)__popcll(m));
+    }
     if (ne) {
       uint64_t* T = row_cells(arena, k.new_base);
       uint32_t nmask = (2u << k.old_lg) - 1u;
@@ -631,12 +639,17 @@ __global__ void k_grow_commit(const Ctl* ctl, const GrowTask* tasks, DirSlot* di
     const GrowTask k = tasks[t];
     DirSlot& d = dir[k.dslot];
     const uint32_t lg = k.old_lg + 1;
+    uint32_t count = k.count;
+    if (lg >= BIG_LG && !k.dup) {                     // k_grow_move's sharded count (fixdup recounts itself)
+      const SubCtr* sc = row_subs(arena, k.new_base, lg);
+      for (uint32_t i = 0; i < SUBS; i++) count += sc[i].cnt;
+    }
     d.meta = META_USED | (lg << META_LG_SHIFT);
     d.base = k.new_base;
-    d.used = k.count;
+    d.used = count;
     if (lg >= BIG_LG) {
       const uint32_t cap = (1u << lg) / 2u + 1u;
-      subs_init(row_subs(arena, k.new_base, lg), cap > k.count ? cap - k.count : 0u);
+      subs_init(row_subs(arena, k.new_base, lg), cap > count ? cap - count : 0u);
     }
   }
 }
