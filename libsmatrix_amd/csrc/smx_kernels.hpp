@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void k_apply(
 // quarter of the stream; their atomics serialise at the memory side (~34 ns each, measured:
 // profiles/r01_*), which alone set the un-aggregated kernel's time.  Here a workgroup first
 // folds its tile of AGG_TILE ops in an LDS hash table keyed by (x,y):
+// (tile = 1024 lanes x 2 ops, 52 KB of LDS, two workgroups per CU)
 //   phase 1  every op CAS-claims/joins its key's LDS slot and atomically adds its value to the
 //            slot's sum; the value the sum had before is the op's prefix inside the tile
 //   phase 2  one lane per DISTINCT key applies the tile's total with the per-op body above
@@ -288,14 +289,18 @@ __global__ __launch_bounds__(256) void k_apply(
 // -- the values a serial execution of the tile's ops in LDS-arrival order returns, i.e. a legal
 // serialisation.  Keys with y == 0 (quirk path) and the all-ones key take the per-op body.
 #ifndef SMX_AGG_OPT
-#define SMX_AGG_OPT 4
+#define SMX_AGG_OPT 2
+#endif
+#ifndef SMX_AGG_THREADS
+#define SMX_AGG_THREADS 1024     /* measured on config 2: 256x4 1.92 ms, 512x4 1.64, 1024x4 1.60, 1024x2 1.55 */
 #endif
 constexpr uint32_t AGG_OPT = SMX_AGG_OPT;          // ops per lane
-constexpr uint32_t AGG_TILE = 256 * AGG_OPT;       // ops per workgroup
+constexpr uint32_t AGG_THREADS = SMX_AGG_THREADS;  // lanes per workgroup
+constexpr uint32_t AGG_TILE = AGG_THREADS * AGG_OPT;   // ops per workgroup
 constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/2)
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_apply_agg(
+__global__ __launch_bounds__(AGG_THREADS) void k_apply_agg(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void k_apply_agg(
   __shared__ uint16_t l_list[AGG_TILE];     // occupied slots, compact
   __shared__ uint32_t l_n;
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < AGG_SLOTS; i += 256) { l_key[i] = ~0ull; l_sum[i] = 0; }
+  for (uint32_t i = tid; i < AGG_SLOTS; i += AGG_THREADS) { l_key[i] = ~0ull; l_sum[i] = 0; }
   if (tid == 0) l_n = 0;
   __syncthreads();
 
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void k_apply_agg(
   // phase 1
 #pragma unroll
   for (uint32_t k = 0; k < AGG_OPT; k++) {
-    const uint32_t t = tile0 + k * 256 + tid;
+    const uint32_t t = tile0 + k * AGG_THREADS + tid;
     slot[k] = ~0u;                 // ~0: no op; ~0-1: per-op path
     if (t >= n) continue;
     j[k] = idx ? idx[t] : t;
@@ -335,22 +340,61 @@ __global__ __launch_bounds__(256) void k_apply_agg(
     slot[k] = h;
   }
   __syncthreads();
-  // phase 2
+  // phase 2: a lane owns up to AGG_OPT distinct keys.  The common case -- directory hit on the
+  // first probe, cell hit on the first probe -- is software-pipelined over the lane's keys (all
+  // directory loads in flight, then all cell loads, then all atomics) so that the three dependent
+  // memory round trips of one key overlap with those of the others; anything else (collision,
+  // insert, missing row) falls back to the generic per-op body.
   const uint32_t nd = l_n;
-  for (uint32_t i = tid; i < nd; i += 256) {
-    const uint32_t h = l_list[i];
-    const uint64_t key = l_key[h];
-    const uint32_t total = l_sum[h];
-    bool deferred = false;
-#if defined(SMX_ABLATE) && SMX_ABLATE == 1       /* timing ablation: no global work in phase 2 */
-    uint32_t res = total;
-#elif defined(SMX_ABLATE) && SMX_ABLATE == 2     /* timing ablation: lookup only, no atomic */
-    uint32_t res = apply_one<OP_GET>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), total, &deferred);
-#else
-    uint32_t res = apply_one<OP>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), total, &deferred);
-#endif
-    l_sum[h] = OP == OP_INCR ? res - total : res + total;    // the cell's value before the tile
-    reinterpret_cast<uint32_t*>(&l_key[h])[0] = deferred ? 1u : 0u;
+  {
+    uint32_t hh[AGG_OPT], tot[AGG_OPT], old[AGG_OPT];
+    uint64_t kk[AGG_OPT];
+    uint4 ds[AGG_OPT];
+    uint64_t cc[AGG_OPT];
+    uint64_t* cp[AGG_OPT];
+    uint32_t fast = 0, have = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < AGG_OPT; q++) {
+      const uint32_t i = tid + q * AGG_THREADS;
+      if (i < nd) {
+        have |= 1u << q;
+        hh[q] = l_list[i];
+        kk[q] = l_key[hh[q]];
+        tot[q] = l_sum[hh[q]];
+        ds[q] = *reinterpret_cast<const uint4*>(&dir[fmix32((uint32_t)kk[q]) & dmask]);
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < AGG_OPT; q++) {
+      if (!(have & (1u << q))) continue;
+      if ((ds[q].x & META_USED) && ds[q].y == (uint32_t)kk[q] && ds[q].z != 0) {
+        const uint32_t Y = (uint32_t)(kk[q] >> 32);
+        cp[q] = row_cells(arena, ds[q].z) + (Y & ((1u << meta_lg(ds[q].x)) - 1u));
+        cc[q] = *cp[q];
+        fast |= 1u << q;
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < AGG_OPT; q++) {
+      if (!(fast & (1u << q))) continue;
+      if (cell_key(cc[q]) == (uint32_t)(kk[q] >> 32)) {
+        uint32_t* vp = reinterpret_cast<uint32_t*>(cp[q]) + 1;
+        old[q] = OP == OP_INCR ? atomicAdd(vp, tot[q]) : atomicSub(vp, tot[q]);
+      } else {
+        fast &= ~(1u << q);
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < AGG_OPT; q++) {
+      if (!(have & (1u << q))) continue;
+      bool deferred = false;
+      if (!(fast & (1u << q))) {
+        uint32_t res = apply_one<OP>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred);
+        old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
+      }
+      l_sum[hh[q]] = old[q];                                  // the cell's value before the tile
+      reinterpret_cast<uint32_t*>(&l_key[hh[q]])[0] = deferred ? 1u : 0u;
+    }
   }
   __syncthreads();
   // phase 3

@@ -252,7 +252,7 @@ void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, con
 template <int OP>
 void launch_apply_agg(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                       const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
-  hipLaunchKernelGGL((k_apply_agg<OP>), dim3(blocks_for(n, AGG_TILE)), dim3(256), 0, s, m->d_ctl,
+  hipLaunchKernelGGL((k_apply_agg<OP>), dim3(blocks_for(n, AGG_TILE)), dim3(AGG_THREADS), 0, s, m->d_ctl,
                      m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   HIP_OK(hipGetLastError());
 }

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Prints the kernel timeline of one bench step from a rocprofv3 kernel-trace dir."""
+import csv, glob, sys
+d = sys.argv[1]; which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
+tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
+idx = [i for i, t in enumerate(tr) if 'k_apply_agg<2>' in t['Kernel_Name'] and t['Grid_Size_X'] == '4194304']
+start = idx[which]; t0 = int(tr[start]['Start_Timestamp'])
+agg = {}
+for t in tr[start:start + 200]:
+    n = t['Kernel_Name'].split('(')[0].replace('void ', '')
+    dur = (int(t['End_Timestamp']) - int(t['Start_Timestamp'])) / 1e3
+    print("%9.1f us  +%8.1f  %-28s grid=%s" % ((int(t['Start_Timestamp']) - t0) / 1e3, dur, n[:28], t['Grid_Size_X']))
+    agg[n] = agg.get(n, 0) + dur
+    if 'k_apply<0>' in n:
+        end = int(t['End_Timestamp']); break
+print("step span %.1f us; kernel time by name:" % ((end - t0) / 1e3))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1]): print("   %-30s %9.1f us" % (k, v))
