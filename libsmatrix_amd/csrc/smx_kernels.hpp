@@ -796,39 +796,98 @@ __global__ __launch_bounds__(256) void k_rowlen(DirSlot* dir, uint32_t dmask, ui
   out[t] = len;
 }
 
-// src/smatrix.c:189-210: one wave per row scans the table in slot order and
-// compacts the non-empty cells (ballot + prefix popcount keeps slot order).
-// Row r may receive at most offsets[r+1]-offsets[r] pairs; counts[r] = pairs written.
+// src/smatrix.c:189-210: the row's table is scanned in slot order and the non-empty cells are
+// compacted (ballot + prefix popcount keeps slot order).  Row r may receive at most
+// offsets[r+1]-offsets[r] pairs; counts[r] = pairs written.
+//   k_getrow      one wave per row, 128 cells (1 KiB) per step with 16-byte loads; rows of more
+//                 than GETROW_WAVE_MAX cells are only noted down in `big`
+//   k_getrow_big  one 1024-lane workgroup per noted row, 2048 cells per step
+constexpr uint32_t GETROW_WAVE_MAX = 8192;
+
+__device__ inline uint32_t getrow_cap(const uint64_t* offsets, uint32_t r) {
+  const uint64_t c = offsets[r + 1] - offsets[r];
+  return c > 0xffffffffull ? 0xffffffffu : (uint32_t)c;
+}
+
 __global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, uint8_t* arena,
                                                 uint32_t n, const uint32_t* __restrict__ xs,
                                                 const uint64_t* __restrict__ offsets,
                                                 uint64_t* __restrict__ ret,
-                                                uint32_t* __restrict__ counts) {
+                                                uint32_t* __restrict__ counts, uint32_t* big) {
   uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
   uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint64_t lt = (1ull << lane) - 1;
   for (uint32_t r = wave; r < n; r += nwaves) {
     uint4 s;
     DirSlot* d = dir_find(dir, dmask, xs[r], &s);
     uint32_t written = 0;
     if (d && s.z != 0) {
-      const uint64_t off = offsets[r];
-      const uint64_t cap64 = offsets[r + 1] - off;
-      const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
       const uint32_t size = 1u << meta_lg(s.x);
-      const uint64_t* cells = row_cells(arena, s.z);
-      for (uint32_t p0 = 0; p0 < size && written < cap; p0 += 64) {
-        uint32_t p = p0 + lane;
-        uint64_t c = p < size ? cells[p] : 0;
-        bool ne = c != 0;
-        uint64_t m = __ballot(ne);
-        uint32_t rank = written + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (ne && rank < cap) ret[off + rank] = c;
-        written += (uint32_t)__popcll(m);
+      if (size > GETROW_WAVE_MAX) {
+        if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = r;
+        continue;
+      }
+      const uint64_t off = offsets[r];
+      const uint32_t cap = getrow_cap(offsets, r);
+      const uint4* cells = reinterpret_cast<const uint4*>(row_cells(arena, s.z));
+      for (uint32_t p0 = 0; p0 < size && written < cap; p0 += 128) {
+        const uint32_t p = p0 + 2 * lane;
+        uint4 c = p < size ? cells[p >> 1] : make_uint4(0, 0, 0, 0);
+        const bool ne0 = (c.x | c.y) != 0, ne1 = (c.z | c.w) != 0;
+        const uint64_t m0 = __ballot(ne0), m1 = __ballot(ne1);
+        uint32_t rank = written + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt);
+        if (ne0 && rank < cap) ret[off + rank] = pack_cell(c.x, c.y);
+        rank += ne0;
+        if (ne1 && rank < cap) ret[off + rank] = pack_cell(c.z, c.w);
+        written += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
       }
       if (written > cap) written = cap;
     }
     if (lane == 0) counts[r] = written;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_getrow_big(DirSlot* dir, uint32_t dmask, uint8_t* arena,
+                                                     const uint32_t* __restrict__ xs,
+                                                     const uint64_t* __restrict__ offsets,
+                                                     uint64_t* __restrict__ ret,
+                                                     uint32_t* __restrict__ counts, const uint32_t* big) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t s_written;
+  const uint32_t nbig = big[0];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1;
+  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+    const uint32_t r = big[1 + b];
+    uint4 s;
+    dir_find(dir, dmask, xs[r], &s);
+    const uint32_t size = 1u << meta_lg(s.x);
+    const uint64_t off = offsets[r];
+    const uint32_t cap = getrow_cap(offsets, r);
+    const uint4* cells = reinterpret_cast<const uint4*>(row_cells(arena, s.z));
+    if (threadIdx.x == 0) s_written = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < size; p0 += 2048) {
+      const uint32_t written = s_written;
+      if (written >= cap) break;
+      const uint4 c = cells[(p0 >> 1) + threadIdx.x];            // size is a multiple of 2048 here
+      const bool ne0 = (c.x | c.y) != 0, ne1 = (c.z | c.w) != 0;
+      const uint64_t m0 = __ballot(ne0), m1 = __ballot(ne1);
+      if (lane == 0) wsum[w] = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+      for (uint32_t i = 0; i < 16; i++) { const uint32_t v = wsum[i]; if (i < w) before += v; total += v; }
+      uint32_t rank = written + before + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt);
+      if (ne0 && rank < cap) ret[off + rank] = pack_cell(c.x, c.y);
+      rank += ne0;
+      if (ne1 && rank < cap) ret[off + rank] = pack_cell(c.z, c.w);
+      __syncthreads();
+      if (threadIdx.x == 0) s_written = written + total;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[r] = s_written > cap ? cap : s_written;
+    __syncthreads();
   }
 }
 

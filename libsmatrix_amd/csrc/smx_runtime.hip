@@ -186,6 +186,7 @@ struct Matrix {
   DevBuf<uint64_t> cellp;
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
   DevBuf<uint64_t> soff;
+  DevBuf<uint32_t> big;                 // getrow: rows too large for one wave
   uint32_t* d_small = nullptr;          // 16 words of scratch
   uint32_t* h_small = nullptr;          // pinned
 
@@ -471,7 +472,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_small) (void)hipHostFree(m->h_small);
       for (auto& d : m->defer) d.release();
       m->tasks.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
-      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release();
+      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
       if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -560,6 +561,20 @@ int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t*
   return 0;
 }
 
+namespace {
+void launch_getrow(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* x, const uint64_t* off,
+                   uint64_t* ret, uint32_t* counts) {
+  m->big.need((size_t)n + 1);
+  HIP_OK(hipMemsetAsync(m->big.p, 0, 4, s));
+  uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
+  hipLaunchKernelGGL(k_getrow, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x,
+                     off, ret, counts, m->big.p);
+  hipLaunchKernelGGL(k_getrow_big, dim3(512), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
+                     x, off, ret, counts, m->big.p);
+  HIP_OK(hipGetLastError());
+}
+}  // namespace
+
 int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,
                              const uint64_t* d_offsets, uint32_t* d_ret, uint32_t* d_counts,
                              void* hip_stream) {
@@ -568,11 +583,7 @@ int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
-  uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
-  hipLaunchKernelGGL(k_getrow, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1,
-                     m->arena.base, (uint32_t)n, d_x, d_offsets,
-                     reinterpret_cast<uint64_t*>(d_ret), d_counts);
-  HIP_OK(hipGetLastError());
+  launch_getrow(m, s, (uint32_t)n, d_x, d_offsets, reinterpret_cast<uint64_t*>(d_ret), d_counts);
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
 }
@@ -590,10 +601,7 @@ int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uin
   dret.need(std::max<uint64_t>(total, 1));
   HIP_OK(hipMemcpyAsync(m->sx.p, x, n * 4, hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(m->soff.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
-  uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
-  hipLaunchKernelGGL(k_getrow, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1,
-                     m->arena.base, (uint32_t)n, m->sx.p, m->soff.p, dret.p, m->so.p);
-  HIP_OK(hipGetLastError());
+  launch_getrow(m, s, (uint32_t)n, m->sx.p, m->soff.p, dret.p, m->so.p);
   HIP_OK(hipMemcpyAsync(counts, m->so.p, n * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   // copy only what was written per row? rows are packed by the caller's offsets: one copy

@@ -391,6 +391,15 @@ def test_big_rows_subcounters(G, oracle_mod, tmp_path):
             assert g.row_info(r) == o.row_info(r), (rnd, r)
         assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
     assert g.stats()["rows_rebalanced"] >= 0
+    # getrow of giant rows goes through the workgroup-per-row kernel: slot order, truncation
+    for r in range(3):
+        slots = np.asarray(g.row_slots(r))
+        ne = slots[(slots[:, 0] != 0) | (slots[:, 1] != 0)]
+        full = g.getrow(r)
+        assert full.shape[0] == ne.shape[0] == o.getrow(r).shape[0] and (full == ne).all()
+        assert (g.getrow(r, 8 * 5000) == ne[:5000]).all() and g.getrow(r, 20).shape[0] == 3
+    off, pairs, cnt = g.m.getrow_batch(np.array([0, 1, 2, 77], dtype=np.uint32))
+    assert cnt.tolist() == [o.rowlen(0), o.rowlen(1), o.rowlen(2), 0]
     # land exactly on thresholds: one op at a time around the 2^15 -> 2^16 doubling of a fresh row
     keys = np.arange(1, (1 << 15) + 40, dtype=np.uint32) * 7
     g.apply(2, np.full(keys.size - 80, 9, np.uint32), keys[:-80], np.ones(keys.size - 80, np.uint32))
