@@ -28,6 +28,16 @@ int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, co
                           uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
                           uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream);
 
+/* Same, but the reordered ops are written as one record {x,y,v} (d_v != NULL, width 3) or {x,y}
+ * (width 2) per op into d_packed, so that a single all-to-all moves them. */
+int smatrix_partition_packed_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
+                                 uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
+                                 uint32_t* d_packed, void* hip_stream);
+
+/* records of `width` words -> separate x/y[/v] arrays (the form the op kernels consume) */
+int smatrix_unpack_dev(size_t n, uint32_t width, const uint32_t* d_packed, uint32_t* d_x, uint32_t* d_y,
+                       uint32_t* d_v, void* hip_stream);
+
 /* d_out[i] = d_src[d_perm[i]] : routes results back into op order */
 int smatrix_gather_dev(size_t n, const uint32_t* d_src, const uint32_t* d_perm, uint32_t* d_out,
                        void* hip_stream);

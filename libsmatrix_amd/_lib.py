@@ -69,6 +69,8 @@ def load():
         # include/smatrix_shard.h
         "smatrix_shard_of": (C.c_uint32, [C.c_uint32, C.c_uint32]),
         "smatrix_partition_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V, V, V]),
+        "smatrix_partition_packed_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V]),
+        "smatrix_unpack_dev": (C.c_int, [C.c_size_t, C.c_uint32, V, V, V, V, V]),
         "smatrix_gather_dev": (C.c_int, [C.c_size_t, V, V, V, V]),
         # include/smx_probe.h
         "smx_probe_random_dev": (C.c_int, [V, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, V, V]),

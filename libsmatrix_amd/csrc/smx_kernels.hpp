@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     uint32_t n, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t nshards, unsigned long long* cursors,
     uint32_t* __restrict__ perm, uint32_t* __restrict__ xo, uint32_t* __restrict__ yo,
-    uint32_t* __restrict__ vo) {
+    uint32_t* __restrict__ vo, uint32_t* __restrict__ packed) {
   __shared__ uint32_t cnt[MAX_SHARDS];
   __shared__ unsigned long long base[MAX_SHARDS];
   if (threadIdx.x < MAX_SHARDS) cnt[threadIdx.x] = 0;
@@ -963,10 +963,28 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     if (sh[k] == ~0u) continue;
     uint32_t dst = (uint32_t)(base[sh[k]] + rk[k]);
     perm[i] = dst;
-    xo[dst] = X[k];
-    yo[dst] = ys[i];
-    if (vs) vo[dst] = vs[i];
+    if (packed) {                       // one {x,y[,v]} record per op: ONE collective moves it
+      const uint32_t w = vs ? 3u : 2u;
+      packed[(uint64_t)dst * w] = X[k];
+      packed[(uint64_t)dst * w + 1] = ys[i];
+      if (vs) packed[(uint64_t)dst * w + 2] = vs[i];
+    } else {
+      xo[dst] = X[k];
+      yo[dst] = ys[i];
+      if (vs) vo[dst] = vs[i];
+    }
   }
+}
+
+// records {x,y[,v]} -> separate arrays (what the op kernels read)
+__global__ __launch_bounds__(256) void k_unpack(uint32_t n, uint32_t width, const uint32_t* __restrict__ packed,
+                                                uint32_t* __restrict__ x, uint32_t* __restrict__ y,
+                                                uint32_t* __restrict__ v) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  x[i] = packed[(uint64_t)i * width];
+  y[i] = packed[(uint64_t)i * width + 1];
+  if (width == 3) v[i] = packed[(uint64_t)i * width + 2];
 }
 
 __global__ __launch_bounds__(256) void k_gather(uint32_t n, const uint32_t* __restrict__ src,

@@ -193,6 +193,7 @@ struct Matrix {
   smatrix_stats_t st = {};
   uint32_t agg_min = 1024;              // batches at least this long fold duplicates in LDS first
   bool profile = false;
+  bool trace_rounds = false;            // SMATRIX_TRACE_ROUNDS=1: one stderr line per round
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
   std::string fname;
@@ -343,6 +344,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
     m->st.rounds++;
+    if (m->trace_rounds)
+      fprintf(stderr, "[smatrix] batch %llu round %u: ops=%u deferred=%u grow=%u rebal=%u dir_full=%u rows=%u\n",
+              (unsigned long long)m->st.batches, round, cur_n, m->h_ctl->n_defer, m->h_ctl->n_tasks,
+              m->h_ctl->n_rebal, m->h_ctl->dir_full, m->h_ctl->dir_used);
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = m->h_ctl->n_defer;
     if (nd == 0) break;
@@ -440,6 +445,7 @@ smatrix_t* smatrix_open(const char* fname) {
   m->arena.init(dev, 4u << 20, m->stream);
   HIP_OK(hipStreamSynchronize(m->stream));
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
+  if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
   const char* prof = getenv("SMATRIX_PROFILE");
   m->profile = prof && *prof == '1';
 
@@ -711,9 +717,10 @@ uint32_t smatrix_row_slots(smatrix_t* self, uint32_t x, uint32_t* kv, uint32_t c
 // ---- sharding helpers (include/smatrix_shard.h) ------------------------------------------------
 uint32_t smatrix_shard_of(uint32_t x, uint32_t nshards) { return shard_of(x, nshards); }
 
-int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
+static int partition_impl(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                           uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
-                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream) {
+                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, uint32_t* d_packed,
+                          void* hip_stream) {
   if (nshards == 0 || nshards > MAX_SHARDS || n >= (1ull << 32)) return -1;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   unsigned long long* work = static_cast<unsigned long long*>(d_work);   // >= 64 * 8 bytes
@@ -730,10 +737,34 @@ int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, co
   HIP_OK(hipMemcpyAsync(work, cur, nshards * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
   if (n) {
     hipLaunchKernelGGL(k_part_scatter, dim3(blocks_for(n, 256 * PART_OPT)), dim3(256), 0, s, (uint32_t)n,
-                       d_x, d_y, d_v, nshards, work, d_perm, d_xo, d_yo, d_vo);
+                       d_x, d_y, d_v, nshards, work, d_perm, d_xo, d_yo, d_vo, d_packed);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(s));   // `cur` lives on this stack frame
+  return 0;
+}
+
+int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
+                          uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
+                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream) {
+  return partition_impl(n, d_x, d_y, d_v, nshards, counts_host, d_work, d_perm, d_xo, d_yo, d_vo, nullptr,
+                        hip_stream);
+}
+
+int smatrix_partition_packed_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
+                                 uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
+                                 uint32_t* d_packed, void* hip_stream) {
+  return partition_impl(n, d_x, d_y, d_v, nshards, counts_host, d_work, d_perm, nullptr, nullptr, nullptr,
+                        d_packed, hip_stream);
+}
+
+int smatrix_unpack_dev(size_t n, uint32_t width, const uint32_t* d_packed, uint32_t* d_x, uint32_t* d_y,
+                       uint32_t* d_v, void* hip_stream) {
+  if (width != 2 && width != 3) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_unpack, dim3(blocks_for(n)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     (uint32_t)n, width, d_packed, d_x, d_y, d_v);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 

@@ -18,6 +18,7 @@ CPU with gloo (tests/test_sharded_gloo.py supplies a CPU partitioner and an orac
 shard); the defaults are the HIP implementations and fail loudly without a GPU.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -67,6 +68,28 @@ class HipPartitioner:
             raise RuntimeError("smatrix_partition_dev failed")
         return [int(c) for c in counts], perm, xo, yo, vo
 
+    def partition_packed(self, x, y, v, world):
+        """-> (counts, perm, packed[n, w]) with w = 3 ({x,y,v}) or 2 ({x,y})"""
+        n = x.numel()
+        counts = (C.c_uint64 * world)()
+        perm = torch.empty(n, dtype=torch.int32, device=x.device)
+        packed = torch.empty((n, 3 if v is not None else 2), dtype=torch.int32, device=x.device)
+        rc = self.lib.smatrix_partition_packed_dev(
+            n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None, world,
+            C.cast(counts, _lib.u64p), self.work.data_ptr(), perm.data_ptr(), packed.data_ptr(), _stream())
+        if rc:
+            raise RuntimeError("smatrix_partition_packed_dev failed")
+        return [int(c) for c in counts], perm, packed
+
+    def unpack(self, packed):
+        n, w = packed.shape
+        x = torch.empty(n, dtype=torch.int32, device=packed.device)
+        y = torch.empty_like(x)
+        v = torch.empty_like(x) if w == 3 else None
+        self.lib.smatrix_unpack_dev(n, w, packed.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                    v.data_ptr() if v is not None else None, _stream())
+        return x, y, v
+
     def gather(self, src, perm, out):
         self.lib.smatrix_gather_dev(out.numel(), src.data_ptr(), perm.data_ptr(), out.data_ptr(), _stream())
 
@@ -83,6 +106,7 @@ class ShardedMatrix:
         self.shard = shard if shard is not None else HipShard()
         self.part = partitioner if partitioner is not None else HipPartitioner(device)
         self.exchanged_ops = 0
+        self.packed = os.environ.get("SMATRIX_SHARD_PACKED", "1") != "0"   # one collective per op batch
 
     @property
     def local(self):
@@ -95,20 +119,31 @@ class ShardedMatrix:
     def apply_dev(self, op, x, y, v, out):
         """x, y, v, out: 1-D int32 tensors on this rank's device (v None for get).
         COLLECTIVE: every rank must call it with the same op (batch sizes may differ)."""
-        counts, perm, xo, yo, vo = self.part.partition(x, y, None if op == OP_GET else v, self.world)
+        vv = None if op == OP_GET else v
+        packed_path = self.packed and hasattr(self.part, "partition_packed")
+        if packed_path:
+            counts, perm, po = self.part.partition_packed(x, y, vv, self.world)
+        else:
+            counts, perm, xo, yo, vo = self.part.partition(x, y, vv, self.world)
         send = torch.tensor(counts, dtype=torch.int64, device=x.device)
         recv = torch.empty(self.world, dtype=torch.int64, device=x.device)
         dist.all_to_all_single(recv, send, group=self.group)
         rcounts = [int(c) for c in recv.tolist()]
         nr = sum(rcounts)
-        xr = torch.empty(nr, dtype=x.dtype, device=x.device)
-        yr = torch.empty(nr, dtype=x.dtype, device=x.device)
-        dist.all_to_all_single(xr, xo, rcounts, counts, group=self.group)
-        dist.all_to_all_single(yr, yo, rcounts, counts, group=self.group)
-        vr = None
-        if op != OP_GET:
-            vr = torch.empty(nr, dtype=x.dtype, device=x.device)
-            dist.all_to_all_single(vr, vo, rcounts, counts, group=self.group)
+        if packed_path:
+            # one collective for the whole op record (splits count rows of the [n, w] tensor)
+            pr = torch.empty((nr, po.shape[1]), dtype=x.dtype, device=x.device)
+            dist.all_to_all_single(pr, po, rcounts, counts, group=self.group)
+            xr, yr, vr = self.part.unpack(pr)
+        else:
+            xr = torch.empty(nr, dtype=x.dtype, device=x.device)
+            yr = torch.empty(nr, dtype=x.dtype, device=x.device)
+            dist.all_to_all_single(xr, xo, rcounts, counts, group=self.group)
+            dist.all_to_all_single(yr, yo, rcounts, counts, group=self.group)
+            vr = None
+            if op != OP_GET:
+                vr = torch.empty(nr, dtype=x.dtype, device=x.device)
+                dist.all_to_all_single(vr, vo, rcounts, counts, group=self.group)
         outr = torch.empty(nr, dtype=x.dtype, device=x.device)
         self.shard.apply(op, xr, yr, vr, outr)
         back = torch.empty(x.numel(), dtype=x.dtype, device=x.device)

@@ -40,6 +40,19 @@ class NumpyPartitioner:
         out.copy_(src[perm.long()])
 
 
+class NumpyPackedPartitioner(NumpyPartitioner):
+    """adds the one-collective record form ([n, w] rows), like HipPartitioner"""
+
+    def partition_packed(self, x, y, v, world):
+        counts, perm, xo, yo, vo = self.partition(x, y, v, world)
+        cols = [xo, yo] + ([vo] if vo is not None else [])
+        return counts, perm, torch.stack(cols, 1).contiguous()
+
+    def unpack(self, packed):
+        return (packed[:, 0].contiguous(), packed[:, 1].contiguous(),
+                packed[:, 2].contiguous() if packed.shape[1] == 3 else None)
+
+
 class OracleShard:
     def __init__(self):
         self.m = O.Oracle()
@@ -60,7 +73,8 @@ def main():
     probe = np.array([0, 1, 2, 12345, 0xFFFFFFFF, 0x80000000, 777777], dtype=np.uint32)
     assert [lib.smatrix_shard_of(int(p), world) for p in probe] == shard_of_np(probe, world).tolist()
 
-    sm = ShardedMatrix(shard=OracleShard(), partitioner=NumpyPartitioner())
+    packed = os.environ.get("SMX_TEST_PACKED") == "1"
+    sm = ShardedMatrix(shard=OracleShard(), partitioner=NumpyPackedPartitioner() if packed else NumpyPartitioner())
     n = 30000 + 1000 * rank                          # ragged batch sizes
     gen = Stream("zipf", 12345 + rank, 50000, 1.1, 1)
     x, y = gen.fill(0, n)

@@ -419,3 +419,24 @@ def test_big_rows_subcounters(G, oracle_mod, tmp_path):
     o2.apply(2, np.zeros(60000, np.uint32), y2, np.ones(60000, np.uint32))
     assert m.row_info(0) == o2.row_info(0) and (m.apply(0, np.zeros(60000, np.uint32), y2) == o2.apply(0, np.zeros(60000, np.uint32), y2)).all()
     m.close(); o2.close(); g.close(); o.close()
+
+
+def test_config1_stock_benchmark_pattern(G, oracle_mod):
+    """BASELINE config 1: the reference benchmark's fixed 23x22 id block (src/smatrix_benchmark.c:29-65),
+    T threads' ops as one batch each for incr then get -- heavy duplication inside a batch"""
+    sys_path = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(
+        __import__("os").path.abspath(__file__))), "tools")
+    __import__("sys").path.insert(0, sys_path)
+    from smatrix_benchmark import pattern
+    g, o = G(), oracle_mod.Oracle()
+    for T in (1, 2, 8, 32):
+        xs, ys = zip(*(pattern(t, 1024 // T) for t in range(T)))
+        x, y = np.concatenate(xs), np.concatenate(ys)
+        assert x.size == 1036288 // 1  # 1024 * 23*22*2 ops per cell of the reference's table
+        ri, ro = g.apply(2, x, y, np.ones_like(x)), o.apply(2, x, y, np.ones_like(x))
+        a, b = per_key_sorted(x, y, ri), per_key_sorted(x, y, ro)
+        assert (a[1] == b[1]).all()
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
+    rows = o.list_rows().tolist()
+    state_equal(g, o, rows, exact_layout=False)
+    g.close(); o.close()
