@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--batch-lg", type=int, default=BATCH_LG)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-lg", type=int, default=23)
+    ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events (A/B of the overhead)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="route through ShardedMatrix even with one rank (exercises the exchange path)")
     args = ap.parse_args()
@@ -149,7 +150,7 @@ def main():
     for s in range(args.warmup):
         step(s)
     local_m = m.local if sharded else m
-    local_m.profile(True)          # HIP events around the op kernels, on the stream they run on
+    local_m.profile(not args.no_profile)          # HIP events around the op kernels, on the stream they run on
     fence()
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
