@@ -440,3 +440,26 @@ def test_config1_stock_benchmark_pattern(G, oracle_mod):
     rows = o.list_rows().tolist()
     state_equal(g, o, rows, exact_layout=False)
     g.close(); o.close()
+
+
+def test_error_convention(G, tmp_path):
+    """src/smatrix.c:92-96: open failure -> NULL (ValueError in the binding);
+    :582-590: a bad header is fatal -- message on stdout, then abort()"""
+    import subprocess, sys, os
+    from libsmatrix_amd import SparseMatrix
+    with pytest.raises(ValueError):
+        SparseMatrix(str(tmp_path / "no_such_dir" / "x.smx"))
+    bad = tmp_path / "bad.smx"
+    bad.write_bytes(b"\x00" * 600)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); from libsmatrix_amd import SparseMatrix; SparseMatrix(%r)"
+                        % (root, str(bad))], capture_output=True, text=True)
+    assert p.returncode == -6 and "libsmatrix error: invalid file header" in p.stdout      # SIGABRT
+    # empty batches and a fresh file are fine
+    m = G(str(tmp_path / "fresh.smx"))
+    assert m.apply(2, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32)).size == 0
+    assert m.rowlen(1) == 0 and m.getrow(1, 64).shape[0] == 0
+    m.close()
+    assert os.path.getsize(str(tmp_path / "fresh.smx")) == 512 + 16 + 4194304 * 12            # SURVEY A.2
+    m = G(str(tmp_path / "fresh.smx")); assert m.get(1, 1) == 0; m.close()
