@@ -58,6 +58,18 @@ int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,
                              const uint64_t* d_offsets, uint32_t* d_ret, uint32_t* d_counts,
                              void* hip_stream);
 
+/* CF-recommender read path, fused (the reference's documented production use,
+ * examples/cf_recommender.c:50-86): for each item a, every neighbour (b, cc) of getrow(a) gets
+ *   score = cc / (sqrt(get(a,0)) * sqrt(get(b,0)))      in double,
+ * with the example's guards (get(b,0) == 0 -> 1; den == 0 -> 0; cc > den -> 0).  Neighbours come in
+ * table slot order; item i writes at most offsets[i+1]-offsets[i] of them at ids/scores + offsets[i];
+ * counts[i] = neighbours written.  Column 0 holds the per-item totals, so quirks Q1/Q2 apply. */
+int smatrix_cf_neighbors_batch(smatrix_t* self, size_t n, const uint32_t* items, const uint64_t* offsets,
+                               uint32_t* ids, double* scores, uint32_t* counts);
+int smatrix_cf_neighbors_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_items,
+                                   const uint64_t* d_offsets, uint32_t* d_ids, double* d_scores,
+                                   uint32_t* d_counts, void* hip_stream);
+
 /* ---- introspection (tests, bench) ---------------------------------------- */
 typedef struct {
   uint64_t rows;            /* rows in the directory */

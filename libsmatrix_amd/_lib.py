@@ -61,6 +61,8 @@ def load():
         "smatrix_apply_batch_dev": (C.c_int, [H, C.c_int, C.c_size_t, V, V, V, V, V]),
         "smatrix_rowlen_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V]),
         "smatrix_getrow_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V, V, V]),
+        "smatrix_cf_neighbors_batch": (C.c_int, [H, C.c_size_t, u32p, u64p, u32p, C.POINTER(C.c_double), u32p]),
+        "smatrix_cf_neighbors_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V, V, V, V]),
         "smatrix_stats": (None, [H, C.POINTER(Stats)]),
         "smatrix_profile": (None, [H, C.c_int]),
         "smatrix_row_info": (C.c_int, [H, C.c_uint32, u32p, u32p]),

@@ -891,6 +891,57 @@ __global__ __launch_bounds__(1024) void k_getrow_big(DirSlot* dir, uint32_t dmas
   }
 }
 
+// ---- CF-recommender read path, fused (examples/cf_recommender.c:50-86) ---------------------------
+// For item a: total = get(a,0); every (b, cc) of getrow(a) scores  cc / (sqrt(total)*sqrt(get(b,0)))
+// with the example's guards (b_total 0 -> 1; den == 0 -> 0; num > den -> 0), all in double.  One wave
+// per item: the row scan of k_getrow, and each lane that holds a neighbour does that neighbour's
+// get(b,0) itself -- 64..128 independent lookups in flight per wave instead of one call per neighbour.
+// Output in slot order like the example's loop; at most offsets[i+1]-offsets[i] neighbours per item.
+__global__ __launch_bounds__(256) void k_cf_neighbors(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n,
+                                                      const uint32_t* __restrict__ items,
+                                                      const uint64_t* __restrict__ offsets,
+                                                      uint32_t* __restrict__ ids, double* __restrict__ scores,
+                                                      uint32_t* __restrict__ counts) {
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint64_t lt = (1ull << lane) - 1;
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    uint4 s;
+    DirSlot* d = dir_find(dir, dmask, items[r], &s);
+    uint32_t written = 0;
+    if (d && s.z != 0) {
+      bool dummy = false;
+      const uint32_t a_total = apply_one<OP_GET>(dir, dmask, arena, items[r], 0u, 0u, &dummy);
+      const double sa = sqrt((double)a_total);
+      const uint32_t size = 1u << meta_lg(s.x);
+      const uint64_t off = offsets[r];
+      const uint32_t cap = getrow_cap(offsets, r);
+      const uint64_t* cells = row_cells(arena, s.z);
+      for (uint32_t p0 = 0; p0 < size && written < cap; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const uint64_t c = p < size ? cells[p] : 0;
+        const bool ne = c != 0;
+        const uint64_t m = __ballot(ne);
+        const uint32_t rank = written + (uint32_t)__popcll(m & lt);
+        if (ne && rank < cap) {
+          uint32_t b_total = apply_one<OP_GET>(dir, dmask, arena, cell_key(c), 0u, 0u, &dummy);
+          if (b_total == 0) b_total = 1;
+          const double num = (double)cell_val(c);
+          const double den = sa * sqrt((double)b_total);
+          double score = 0.0;
+          if (den != 0.0 && !(num > den)) score = num / den;
+          ids[off + rank] = cell_key(c);
+          scores[off + rank] = score;
+        }
+        written += (uint32_t)__popcll(m);
+      }
+      if (written > cap) written = cap;
+    }
+    if (lane == 0) counts[r] = written;
+  }
+}
+
 // ---- debug / export helpers -------------------------------------------------------
 __global__ void k_row_info(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t x, uint32_t* out4) {
   uint4 s;

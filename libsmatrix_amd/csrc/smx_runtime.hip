@@ -616,6 +616,49 @@ int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uin
   return 0;
 }
 
+// ---- CF-recommender read path (include/smatrix_batch.h) ------------------------------------------
+int smatrix_cf_neighbors_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_items,
+                                   const uint64_t* d_offsets, uint32_t* d_ids, double* d_scores,
+                                   uint32_t* d_counts, void* hip_stream) {
+  if (n == 0) return 0;
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
+  hipLaunchKernelGGL(k_cf_neighbors, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
+                     (uint32_t)n, d_items, d_offsets, d_ids, d_scores, d_counts);
+  HIP_OK(hipGetLastError());
+  if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int smatrix_cf_neighbors_batch(smatrix_t* self, size_t n, const uint32_t* items, const uint64_t* offsets,
+                               uint32_t* ids, double* scores, uint32_t* counts) {
+  if (n == 0) return 0;
+  Matrix* m = M(self);
+  set_device(m);
+  const uint64_t total = offsets[n];
+  uint32_t *d_items = nullptr, *d_ids = nullptr, *d_counts = nullptr;
+  uint64_t* d_off = nullptr;
+  double* d_scores = nullptr;
+  HIP_OK(hipMalloc(&d_items, n * 4));
+  HIP_OK(hipMalloc(&d_off, (n + 1) * 8));
+  HIP_OK(hipMalloc(&d_counts, n * 4));
+  HIP_OK(hipMalloc(&d_ids, std::max<uint64_t>(total, 1) * 4));
+  HIP_OK(hipMalloc(&d_scores, std::max<uint64_t>(total, 1) * 8));
+  HIP_OK(hipMemcpy(d_items, items, n * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice));
+  smatrix_cf_neighbors_batch_dev(self, n, d_items, d_off, d_ids, d_scores, d_counts, nullptr);
+  HIP_OK(hipMemcpy(counts, d_counts, n * 4, hipMemcpyDeviceToHost));
+  if (total) {
+    HIP_OK(hipMemcpy(ids, d_ids, total * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(scores, d_scores, total * 8, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_items); (void)hipFree(d_off); (void)hipFree(d_counts); (void)hipFree(d_ids); (void)hipFree(d_scores);
+  return 0;
+}
+
 // ---- the reference's scalar entry points: one-op batches --------------------------
 static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint32_t v) {
   Matrix* m = M(self);

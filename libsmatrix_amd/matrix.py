@@ -124,6 +124,21 @@ class SparseMatrix:
                                        pairs.ctypes.data_as(_lib.u32p), _p(counts))
         return offsets, pairs, counts
 
+    def cf_neighbors_batch(self, items, caps=None):
+        """CF-recommender read path (examples/cf_recommender.c:50-86), fused on the GPU:
+        -> (offsets[n+1], ids[total], scores[total] float64, counts[n])"""
+        items = _u32(items)
+        if caps is None:
+            caps = self.rowlen_batch(items).astype(np.uint64) + 1
+        offsets = np.zeros(items.size + 1, dtype=np.uint64)
+        np.cumsum(np.asarray(caps, dtype=np.uint64), out=offsets[1:])
+        ids = np.zeros(int(offsets[-1]), dtype=np.uint32)
+        scores = np.zeros(int(offsets[-1]), dtype=np.float64)
+        counts = np.zeros(items.size, dtype=np.uint32)
+        self._lib.smatrix_cf_neighbors_batch(self._h, items.size, _p(items), offsets.ctypes.data_as(_lib.u64p),
+                                             _p(ids), scores.ctypes.data_as(C.POINTER(C.c_double)), _p(counts))
+        return offsets, ids, scores, counts
+
     # device-pointer flavours (raw pointers; stream = hipStream_t as int or None)
     def apply_batch_dev(self, op, n, x_ptr, y_ptr, v_ptr, out_ptr, stream=None):
         self._lib.smatrix_apply_batch_dev(self._h, op, n, x_ptr, y_ptr, v_ptr, out_ptr, stream)

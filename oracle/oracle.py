@@ -180,6 +180,18 @@ def Oracle(fname=None):
     return _cache["o"](fname)
 
 
+def cf_neighbors(oracle_handle, item, cap):
+    """ora_cf_neighbors on an Oracle instance -> (ids, scores)"""
+    lib = oracle_handle._lib
+    fn = lib.ora_cf_neighbors
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_void_p, C.c_uint32, _u32p, C.POINTER(C.c_double), C.c_uint32]
+    ids = np.zeros(max(cap, 1), dtype=np.uint32)
+    sc = np.zeros(max(cap, 1), dtype=np.float64)
+    n = fn(oracle_handle._h, item, _ptr(ids), sc.ctypes.data_as(C.POINTER(C.c_double)), cap)
+    return ids[:n], sc[:n]
+
+
 def Reference(fname=None):
     if "r" not in _cache:
         if not have_reference():

@@ -432,6 +432,31 @@ uint64_t ora_sum_get(ora_matrix_t* m, size_t n, const uint32_t* x, const uint32_
   return s;
 }
 
+/* examples/cf_recommender.c:50-64 neighbors_for_item + :67-86 cf_cosine.  (The example does not
+ * compile as shipped -- missing brace at :50-51, undeclared `pset` -- so this follows its evident
+ * intent: total = get(item,0); for each getrow pair (b, cc): cc / (sqrt(total)*sqrt(get(b,0))),
+ * get(b,0)==0 -> 1, den==0 -> 0, cc > den -> 0.) */
+#include <math.h>
+uint32_t ora_cf_neighbors(ora_matrix_t* m, uint32_t item, uint32_t* ids, double* scores, uint32_t cap) {
+  row_t* r = dir_lookup(m, item, 0);
+  uint32_t n = 0;
+  if (!r) return 0;
+  uint32_t a_total = ora_get(m, item, 0);
+  for (uint32_t p = 0; p < r->size && n < cap; p++) {
+    if (cell_is_empty(&r->cells[p])) continue;
+    uint32_t b_total = ora_get(m, r->cells[p].key, 0);
+    if (b_total == 0) b_total = 1;
+    double num = r->cells[p].value;
+    double den = sqrt((double)a_total) * sqrt((double)b_total);
+    double score = 0.0;
+    if (den != 0.0 && !(num > den)) score = num / den;
+    ids[n] = r->cells[p].key;
+    scores[n] = score;
+    n++;
+  }
+  return n;
+}
+
 uint64_t ora_num_rows(ora_matrix_t* m) { return m->dir_used; }
 uint64_t ora_dir_size(ora_matrix_t* m) { return m->dir_size; }
 uint64_t ora_mem(ora_matrix_t* m) { return m->mem; }

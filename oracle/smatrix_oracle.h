@@ -51,6 +51,10 @@ void ora_apply(ora_matrix_t* m, int op, size_t n, const uint32_t* x,
 /* sum of get(x_i, y_i) over a stream (SURVEY.md A.4 checksum) */
 uint64_t ora_sum_get(ora_matrix_t* m, size_t n, const uint32_t* x, const uint32_t* y);
 
+/* CF-recommender read path as the example intends it (examples/cf_recommender.c:50-86): neighbours of
+ * `item` in getrow (slot) order with their cosine scores; returns the count (<= cap) */
+uint32_t ora_cf_neighbors(ora_matrix_t* m, uint32_t item, uint32_t* ids, double* scores, uint32_t cap);
+
 /* introspection: row table geometry and raw slots (slot order) */
 uint64_t ora_num_rows(ora_matrix_t* m);              /* cmap.used  */
 uint64_t ora_dir_size(ora_matrix_t* m);              /* cmap.size  */

@@ -463,3 +463,38 @@ def test_error_convention(G, tmp_path):
     m.close()
     assert os.path.getsize(str(tmp_path / "fresh.smx")) == 512 + 16 + 4194304 * 12
     m = G(str(tmp_path / "fresh.smx")); assert m.get(1, 1) == 0; m.close()
+
+
+def test_cf_recommender_read_path(G, oracle_mod):
+    """examples/cf_recommender.c: import preference sets (incr(id,0,1) + co-occurrence incrs), then the
+    fused neighbours+cosine kernel against the oracle's restatement.  double arithmetic: sqrt and
+    division are correctly rounded on both sides -> tolerance 1e-15 relative (expected: bit-equal)"""
+    rng = np.random.default_rng(8)
+    xs, ys = [], []
+    for _ in range(4000):                                        # preference sets of 2..8 items out of 600
+        ids = rng.choice(600, size=int(rng.integers(2, 9)), replace=False) + 1
+        for a in ids:
+            xs.append(a); ys.append(0)                           # :38  total per item in column 0 (quirk Q1)
+            for b in ids:
+                if a != b:
+                    xs.append(a); ys.append(b)                   # :40-44
+    x, y = np.array(xs, np.uint32), np.array(ys, np.uint32)
+    g, o = G(), oracle_mod.Oracle()
+    g.apply(2, x, y, np.ones_like(x)); o.apply(2, x, y, np.ones_like(x))
+    items = np.arange(0, 640, dtype=np.uint32)                   # includes absent items
+    off, ids, sc, cnt = g.m.cf_neighbors_batch(items)
+    worst = 0.0
+    for i, it in enumerate(items.tolist()):
+        wi, ws = oracle_mod.cf_neighbors(o, it, 100000)
+        assert cnt[i] == wi.size
+        mine_i, mine_s = ids[off[i]: off[i] + cnt[i]], sc[off[i]: off[i] + cnt[i]]
+        a, b = np.argsort(mine_i, kind="stable"), np.argsort(wi, kind="stable")   # batch layout may differ
+        assert (mine_i[a] == wi[b]).all()
+        if wi.size:
+            worst = max(worst, float(np.max(np.abs(mine_s[a] - ws[b]) / np.maximum(ws[b], 1e-300))))
+    assert worst <= 1e-15, worst
+    assert sc.max() <= 1.0 and sc.min() >= 0.0 and (sc > 0).any()
+    # truncation like the example's 8192-byte buffer (1024 pairs)
+    off, ids, sc, cnt = g.m.cf_neighbors_batch(items, caps=np.full(items.size, 5, np.uint64))
+    assert cnt.max() == 5
+    g.close(); o.close()
