@@ -11,7 +11,9 @@ warmup + steps = 24 batches cover the whole 4e8-op stream (100.4M nnz in 1M rows
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank draws its
 own slice of the stream, ops are routed to the row's owner shard with all_to_all
-(libsmatrix_amd/sharded.py) and results routed back.  scaling = weak.
+(libsmatrix_amd/sharded.py) and results routed back; the exchange of get(s) overlaps the
+incr kernels of step s and the exchange of incr(s+1) overlaps get(s) (split-phase API on a
+separate communication stream).  scaling = weak.
 
 Prints ONE JSON line on rank 0.
 """
@@ -106,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-lg", type=int, default=26)
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events (A/B of the overhead)")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded path: one blocking apply_dev per op batch")
     ap.add_argument("--force-sharded", action="store_true",
                     help="route through ShardedMatrix even with one rank (exercises the exchange path)")
     args = ap.parse_args()
@@ -147,8 +150,21 @@ def main():
     else:
         m = SparseMatrix()
 
+    pending = {}       # sharded: batches whose incr records are already travelling (routed ahead)
+
     def step(s):
-        if sharded:
+        if sharded and not args.no_overlap:
+            # exchange of get(s) overlaps the incr kernels of s; exchange of incr(s+1) overlaps get(s)
+            h_i = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones)
+            h_g = m.route(OP_GET, xs[s], ys[s])
+            m.apply_routed(h_i)
+            m.finish(h_i, out_i)
+            if s + 1 < total_steps and s + 1 != args.warmup:      # never across the timing fence
+                pending[s + 1] = m.route(OP_INCR, xs[s + 1], ys[s + 1], ones)
+            m.apply_routed(h_g)
+            m.finish(h_g, out_g)
+            m.wait(h_i); m.wait(h_g)
+        elif sharded:
             m.apply_dev(OP_INCR, xs[s], ys[s], ones, out_i)
             m.apply_dev(OP_GET, xs[s], ys[s], None, out_g)
         else:

@@ -152,5 +152,102 @@ class ShardedMatrix:
         self.exchanged_ops += nr
         return out
 
+    # ---- split-phase form: lets the exchange of one batch overlap the op kernels of another -------
+    #
+    #   h = route(op, x, y, v)     partition + all_to_all of the op records   (communication stream)
+    #   apply_routed(h)            the owner's op kernels on what arrived      (compute stream)
+    #   finish(h, out)             all_to_all of the results back + gather     (communication stream)
+    #   wait(h)                    compute stream waits for `out`
+    #
+    # route() of batch B may be issued before apply_routed() of batch A returns to the host: the
+    # library blocks the host only on the compute stream, so the records of B travel while A's kernels
+    # run.  bench.py pipelines  incr(s) | get(s) | incr(s+1)  this way.  On CPU tensors (gloo tests)
+    # there are no streams and the phases simply run in order.
+    class _Routed:
+        pass
+
+    def _comm(self, like):
+        if not like.is_cuda:
+            return None
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(device=like.device)
+        return self._comm_stream
+
+    def route(self, op, x, y, v=None):
+        h = self._Routed()
+        h.op, h.n, h.x_dev = op, x.numel(), x.device
+        comm = self._comm(x)
+        vv = None if op == OP_GET else v
+        ctx = torch.cuda.stream(comm) if comm is not None else _null_ctx()
+        if comm is not None:
+            comm.wait_stream(torch.cuda.current_stream())         # inputs were produced on the compute stream
+        with ctx:
+            packed_path = self.packed and hasattr(self.part, "partition_packed")
+            if packed_path:
+                h.counts, h.perm, po = self.part.partition_packed(x, y, vv, self.world)
+            else:
+                h.counts, h.perm, xo, yo, vo = self.part.partition(x, y, vv, self.world)
+            send = torch.tensor(h.counts, dtype=torch.int64, device=x.device)
+            recv = torch.empty(self.world, dtype=torch.int64, device=x.device)
+            dist.all_to_all_single(recv, send, group=self.group)
+            h.rcounts = [int(c) for c in recv.tolist()]
+            nr = sum(h.rcounts)
+            if packed_path:
+                pr = torch.empty((nr, po.shape[1]), dtype=x.dtype, device=x.device)
+                dist.all_to_all_single(pr, po, h.rcounts, h.counts, group=self.group)
+                h.xr, h.yr, h.vr = self.part.unpack(pr)
+                h.keep = (x, y, v, po, pr)
+            else:
+                h.xr = torch.empty(nr, dtype=x.dtype, device=x.device)
+                h.yr = torch.empty(nr, dtype=x.dtype, device=x.device)
+                dist.all_to_all_single(h.xr, xo, h.rcounts, h.counts, group=self.group)
+                dist.all_to_all_single(h.yr, yo, h.rcounts, h.counts, group=self.group)
+                h.vr = None
+                if vv is not None:
+                    h.vr = torch.empty(nr, dtype=x.dtype, device=x.device)
+                    dist.all_to_all_single(h.vr, vo, h.rcounts, h.counts, group=self.group)
+                h.keep = (x, y, v, xo, yo, vo)
+            h.outr = torch.empty(nr, dtype=x.dtype, device=x.device)
+            h.ev_routed = comm.record_event() if comm is not None else None
+        self.exchanged_ops += nr
+        return h
+
+    def apply_routed(self, h):
+        if h.ev_routed is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(h.ev_routed)
+            for t in (h.xr, h.yr, h.vr, h.outr):
+                if t is not None:
+                    t.record_stream(cur)                          # allocated under the communication stream
+        self.shard.apply(h.op, h.xr, h.yr, h.vr, h.outr)
+        h.ev_applied = torch.cuda.current_stream().record_event() if h.ev_routed is not None else None
+
+    def finish(self, h, out):
+        comm = self._comm(out)
+        ctx = torch.cuda.stream(comm) if comm is not None else _null_ctx()
+        with ctx:
+            if comm is not None:
+                comm.wait_event(h.ev_applied)
+                out.record_stream(comm)
+            back = torch.empty(h.n, dtype=out.dtype, device=out.device)
+            dist.all_to_all_single(back, h.outr, h.counts, h.rcounts, group=self.group)
+            self.part.gather(back, h.perm, out)
+            h.ev_done = comm.record_event() if comm is not None else None
+            h.keep = h.keep + (back,)
+        return h
+
+    def wait(self, h):
+        if getattr(h, "ev_done", None) is not None:
+            torch.cuda.current_stream().wait_event(h.ev_done)
+        h.keep = None
+
     def close(self):
         self.shard.close()
+
+
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

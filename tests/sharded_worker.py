@@ -81,8 +81,16 @@ def main():
     xt, yt = torch.from_numpy(x.view(np.int32)), torch.from_numpy(y.view(np.int32))
     ones = torch.ones(n, dtype=torch.int32)
     out_i = torch.empty(n, dtype=torch.int32); out_g = torch.empty(n, dtype=torch.int32)
-    sm.apply_dev(2, xt, yt, ones, out_i)
-    sm.apply_dev(0, xt, yt, None, out_g)
+    if os.environ.get("SMX_TEST_SPLIT") == "1":
+        # split-phase form, issued in bench.py's pipelined order: route(get) before apply(incr)
+        h_i = sm.route(2, xt, yt, ones)
+        h_g = sm.route(0, xt, yt)
+        sm.apply_routed(h_i); sm.finish(h_i, out_i)
+        sm.apply_routed(h_g); sm.finish(h_g, out_g)
+        sm.wait(h_i); sm.wait(h_g)
+    else:
+        sm.apply_dev(2, xt, yt, ones, out_i)
+        sm.apply_dev(0, xt, yt, None, out_g)
     # an empty batch on one rank must not hang the collective
     e = torch.empty(0, dtype=torch.int32)
     sm.apply_dev(0, e if rank == 0 else xt[:10], e if rank == 0 else yt[:10], None,

@@ -498,3 +498,13 @@ def test_cf_recommender_read_path(G, oracle_mod):
     off, ids, sc, cnt = g.m.cf_neighbors_batch(items, caps=np.full(items.size, 5, np.uint64))
     assert cnt.max() == 5
     g.close(); o.close()
+
+
+def test_sharded_pipeline_matches_direct():
+    """split-phase ShardedMatrix with its own communication stream (the form bench.py pipelines at N>1)
+    against the direct path, one rank over RCCL: identical get results and per-key incr returns"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "sharded_gpu_check.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "SHARDED_PIPELINE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
