@@ -16,8 +16,10 @@
  *
  * Two flavours: host pointers (staged through HBM by the library) and `_dev`
  * (pointers are device memory on the matrix's GPU; work is enqueued on
- * `hip_stream` -- a hipStream_t passed as void*, NULL = the matrix's own stream --
- * and the call returns after the result is complete on that stream).
+ * `hip_stream` -- a hipStream_t passed as void*, NULL = the matrix's own stream.
+ * Results are complete in stream order: writers return after their last round has
+ * finished on that stream, get/rowlen/getrow may return as soon as they are enqueued;
+ * with hip_stream == NULL every call synchronises before returning).
  * Return value: 0 on success; failures abort like the scalar API.
  * n must be < 2^32.
  */

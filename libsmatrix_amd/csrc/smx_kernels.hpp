@@ -274,6 +274,17 @@ __global__ __launch_bounds__(256) void k_apply(
   if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
 }
 
+// ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
+// res[0] = value, res[1] = 1 if a structure change is needed first (the host then takes the round loop)
+template <int OP>
+__global__ void k_scalar(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X, uint32_t Y, uint32_t V,
+                         volatile uint32_t* res) {
+  bool deferred = false;
+  uint32_t r = apply_one<OP>(dir, dmask, arena, X, Y, V, &deferred);
+  res[0] = r;
+  res[1] = deferred ? 1u : 0u;
+}
+
 // ---- op kernel with in-tile aggregation (incr / decr) -----------------------------
 //
 // Under Zipf(1.1) x Zipf(1.1) 1.5 % of all ops hit ONE cell and a few dozen cells take a

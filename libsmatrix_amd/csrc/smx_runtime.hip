@@ -98,6 +98,7 @@ struct Arena {
   void grow_to(size_t bytes, size_t live, hipStream_t st) {
     if (bytes <= mapped) return;
     if (vmm) {
+      HIP_OK(hipStreamSynchronize(st));   // nothing may be running on the range while its access is re-set
       size_t add = (bytes - mapped + gran - 1) / gran * gran;
       if (mapped + add > reserved) smx_die("row arena exhausted (all of HBM reserved)");
       hipMemAllocationProp prop = {};
@@ -665,6 +666,24 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
   hipStream_t s = m->stream;
+  // fast path: one launch, result written by the kernel into pinned host memory, one sync.
+  // (set keeps its value write inside apply_one; a one-op batch has no duplicates to resolve)
+  {
+    volatile uint32_t* res = m->h_small + 8;
+    const dim3 one(1);
+    switch (op) {
+      case OP_GET:  hipLaunchKernelGGL((k_scalar<OP_GET>), one, one, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, x, y, v, res); break;
+      case OP_SET:  hipLaunchKernelGGL((k_scalar<OP_SET>), one, one, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, x, y, v, res); break;
+      case OP_INCR: hipLaunchKernelGGL((k_scalar<OP_INCR>), one, one, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, x, y, v, res); break;
+      default:      hipLaunchKernelGGL((k_scalar<OP_DECR>), one, one, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, x, y, v, res); break;
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(s));
+    if (!res[1]) {
+      if (op != OP_GET) m->st.batches++;
+      return res[0];
+    }
+  }
   m->h_small[0] = x; m->h_small[1] = y; m->h_small[2] = v;
   HIP_OK(hipMemcpyAsync(m->d_small, m->h_small, 12, hipMemcpyHostToDevice, s));
   apply_dev_locked(self, op, 1, m->d_small, m->d_small + 1, m->d_small + 2, m->d_small + 3, s);

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""GPU probe: latency of the scalar (drop-in) ABI."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from libsmatrix_amd import SparseMatrix
+m = SparseMatrix()
+N = 20000
+t0 = time.perf_counter()
+for i in range(N): m.incr(i % 500, 1 + i % 97, 1)
+t1 = time.perf_counter()
+for i in range(N): m.get(i % 500, 1 + i % 97)
+t2 = time.perf_counter()
+for i in range(N): m.set(1000 + i, 1 + i, 5)        # every op creates a row
+t3 = time.perf_counter()
+print("scalar incr %.1f us/op, get %.1f us/op, set(new row) %.1f us/op" % ((t1 - t0) / N * 1e6, (t2 - t1) / N * 1e6, (t3 - t2) / N * 1e6))
+m.close()
