@@ -199,7 +199,9 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
         uint32_t* ticket;
         if (lg >= BIG_LG) {
           // big row: take the ticket from one of the sub-counters (its quota is a share of the room)
-          SubCtr* sc = row_subs(arena, s.z, lg) + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (SUBS - 1u));
+          // (spread by lane as well: a handful of retried ops all sit in one wave and must not
+          //  queue on the single share of one sub-counter)
+          SubCtr* sc = row_subs(arena, s.z, lg) + ((blockIdx.x * 5u + threadIdx.x) & (SUBS - 1u));
           const uint2 cq = *reinterpret_cast<const uint2*>(sc);      // {cnt, quota}; quota is stable here
           if (cq.x >= cq.y) { *deferred = true; return 0; }
           ticket = &sc->cnt;
