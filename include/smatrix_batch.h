@@ -16,7 +16,9 @@
  *
  * Two flavours: host pointers (staged through HBM by the library) and `_dev`
  * (pointers are device memory on the matrix's GPU; work is enqueued on
- * `hip_stream` -- a hipStream_t passed as void*, NULL = the matrix's own stream.
+ * `hip_stream` -- a hipStream_t passed as void*; NULL = the legacy default stream, i.e. what
+ * `torch.cuda.current_stream().cuda_stream` is unless the caller switched streams, so inputs
+ * produced by earlier work on that stream are ordered before the kernels that read them.
  * Results are complete in stream order: writers return after their last round has
  * finished on that stream, get/rowlen/getrow may return as soon as they are enqueued;
  * with hip_stream == NULL every call synchronises before returning).

@@ -496,7 +496,7 @@ int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
-  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   apply_dev_locked(self, op, n, d_x, d_y, d_v, d_out, s);
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -544,7 +544,7 @@ int smatrix_rowlen_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x, uin
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
-  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   hipLaunchKernelGGL(k_rowlen, dim3(blocks_for(n)), dim3(256), 0, s, m->d_dir, m->dir_size - 1,
                      m->arena.base, (uint32_t)n, d_x, d_out);
   HIP_OK(hipGetLastError());
@@ -589,7 +589,7 @@ int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
-  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   launch_getrow(m, s, (uint32_t)n, d_x, d_offsets, reinterpret_cast<uint64_t*>(d_ret), d_counts);
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -625,7 +625,7 @@ int smatrix_cf_neighbors_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
-  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->stream;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
   hipLaunchKernelGGL(k_cf_neighbors, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
                      (uint32_t)n, d_items, d_offsets, d_ids, d_scores, d_counts);

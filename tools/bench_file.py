@@ -31,9 +31,16 @@ def main():
         m.apply_batch_dev(OP_INCR, x.numel(), x.data_ptr(), y.data_ptr(), ones.data_ptr(), out.data_ptr(), st)
         if keep is None:
             keep = (x.clone(), y.clone())
+        last = (x, y)
     torch.cuda.synchronize()
     want = torch.empty_like(keep[0])
     m.apply_batch_dev(OP_GET, want.numel(), keep[0].data_ptr(), keep[1].data_ptr(), None, want.data_ptr(), st)
+    torch.cuda.synchronize()
+    want_last = torch.empty_like(last[0])
+    m.apply_batch_dev(OP_GET, want_last.numel(), last[0].data_ptr(), last[1].data_ptr(), None, want_last.data_ptr(), st)
+    xs0 = as_i32(fmix32(torch.arange(1, a.rows + 1, device=dev, dtype=torch.int64)))
+    lens0 = torch.empty(a.rows, dtype=torch.int32, device=dev)
+    m.rowlen_batch_dev(a.rows, xs0.data_ptr(), lens0.data_ptr(), st)
     torch.cuda.synchronize()
     rows_before = m.stats()["rows"]
     t0 = time.perf_counter(); m.close(); t_close = time.perf_counter() - t0
@@ -44,7 +51,10 @@ def main():
     e0.record()
     m.apply_batch_dev(OP_GET, got.numel(), keep[0].data_ptr(), keep[1].data_ptr(), None, got.data_ptr(), st)
     e1.record(); torch.cuda.synchronize()
-    ok = bool(torch.equal(got, want)) and m.stats()["rows"] == rows_before
+    got_last = torch.empty_like(want_last)
+    m.apply_batch_dev(OP_GET, got_last.numel(), last[0].data_ptr(), last[1].data_ptr(), None, got_last.data_ptr(), st)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(got, want)) and bool(torch.equal(got_last, want_last)) and m.stats()["rows"] == rows_before
     xs = as_i32(fmix32(torch.arange(1, a.rows + 1, device=dev, dtype=torch.int64)))
     lens = torch.empty(a.rows, dtype=torch.int32, device=dev)
     m.rowlen_batch_dev(a.rows, xs.data_ptr(), lens.data_ptr(), st)
@@ -54,6 +64,8 @@ def main():
     e2.record(); m.getrow_batch_dev(a.rows, xs.data_ptr(), off.data_ptr(), ret.data_ptr(), cnt.data_ptr(), st); e3.record()
     torch.cuda.synchronize()
     nnz = int(cnt.long().sum().item())
+    ok = ok and bool(torch.equal(lens, lens0)) and nnz == int(lens0.long().sum().item())
+    print("sum rowlen before %d after %d getrow %d" % (int(lens0.long().sum()), int(lens.long().sum()), nnz), file=sys.stderr)
     print(json.dumps({"metric": "file-backed round trip", "rows": a.rows, "nnz": nnz, "file_bytes": fbytes,
                       "close_s": t_close, "write_GBps": fbytes / t_close / 1e9, "open_s": t_open,
                       "load_GBps": fbytes / t_open / 1e9, "verified": ok,
