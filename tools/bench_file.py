@@ -33,6 +33,7 @@ def main():
             keep = (x.clone(), y.clone())
         last = (x, y)
     torch.cuda.synchronize()
+    print("built", m.stats(), file=sys.stderr, flush=True)
     want = torch.empty_like(keep[0])
     m.apply_batch_dev(OP_GET, want.numel(), keep[0].data_ptr(), keep[1].data_ptr(), None, want.data_ptr(), st)
     torch.cuda.synchronize()
@@ -43,9 +44,12 @@ def main():
     m.rowlen_batch_dev(a.rows, xs0.data_ptr(), lens0.data_ptr(), st)
     torch.cuda.synchronize()
     rows_before = m.stats()["rows"]
+    print("closing", file=sys.stderr, flush=True)
     t0 = time.perf_counter(); m.close(); t_close = time.perf_counter() - t0
+    print("closed", file=sys.stderr, flush=True)
     fbytes = os.path.getsize(a.path)
     t0 = time.perf_counter(); m = SparseMatrix(a.path); t_open = time.perf_counter() - t0
+    print("reopened", m.stats(), file=sys.stderr, flush=True)
     got = torch.empty_like(want)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -55,6 +59,7 @@ def main():
     m.apply_batch_dev(OP_GET, got_last.numel(), last[0].data_ptr(), last[1].data_ptr(), None, got_last.data_ptr(), st)
     torch.cuda.synchronize()
     ok = bool(torch.equal(got, want)) and bool(torch.equal(got_last, want_last)) and m.stats()["rows"] == rows_before
+    print("gets after reopen done", file=sys.stderr, flush=True)
     xs = as_i32(fmix32(torch.arange(1, a.rows + 1, device=dev, dtype=torch.int64)))
     lens = torch.empty(a.rows, dtype=torch.int32, device=dev)
     m.rowlen_batch_dev(a.rows, xs.data_ptr(), lens.data_ptr(), st)
