@@ -433,7 +433,9 @@ smatrix_t* smatrix_open(const char* fname) {
   else HIP_OK(hipGetDevice(&dev));
   m->device = dev;
   set_device(m);
-  HIP_OK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  // a BLOCKING stream: ordered against the legacy default stream, so host-pointer calls (this stream)
+  // and device-pointer calls with hip_stream == NULL (the default stream) never overlap each other
+  HIP_OK(hipStreamCreate(&m->stream));
   HIP_OK(hipMalloc(&m->d_ctl, sizeof(Ctl)));
   HIP_OK(hipHostMalloc(&m->h_ctl, sizeof(Ctl)));
   HIP_OK(hipMalloc(&m->d_small, 64));
