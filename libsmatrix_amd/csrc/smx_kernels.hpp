@@ -53,7 +53,7 @@ __host__ __device__ inline uint64_t units_of_lg(uint32_t lg) { return 1ull << (l
 //   rowlen = used + sum(cnt)   at any quiescent point.
 constexpr uint32_t META_REBAL = 1u << 17;  // quotas want re-partitioning (k_rebal)
 constexpr uint32_t BIG_LG = 15;
-constexpr uint32_t SUBS = 16;
+constexpr uint32_t SUBS = 64;     // 4 KB per big row (>= 256 KB of cells)
 constexpr uint32_t SUB_UNITS = SUBS * 64 / 128;
 struct SubCtr { uint32_t cnt, quota, pad[14]; };
 static_assert(sizeof(SubCtr) == 64, "one sub-counter per 64-byte line");
@@ -453,84 +453,138 @@ __global__ __launch_bounds__(AGG_THREADS) void k_apply_agg(
 //  * flags a row for growth iff the op's key is ABSENT and the row stands at the
 //    reference's threshold -- the exact condition under which the reference's
 //    next insert would call smatrix_rmap_resize (src/smatrix.c:346-348).
+// One leader per distinct 32-bit key among the lanes of this wave that `want`: calls f(key) on the
+// leader lane only.  Deferred ops cluster on few rows (a row at its threshold defers every new key),
+// and every expensive step of prep -- the creation protocol, the sub-counter sum, the flag atomics --
+// is per ROW, not per op: without the election a million lanes hammered the same directory word
+// (measured: 5.6 ms of a 9.5 ms step).
+template <typename F>
+__device__ inline void per_distinct(bool want, uint32_t key, F f) {
+  // election first (ALU + ballots only), then ALL leaders run f together so that their memory
+  // round trips overlap -- running f inside the loop would serialise a wave with 64 distinct rows
+  uint64_t todo = __ballot(want);
+  const uint32_t lane = __lane_id();
+  bool leader_here = false;
+  while (todo) {
+    const uint32_t leader = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t k0 = __shfl(key, leader);
+    todo &= ~__ballot(want && key == k0);
+    leader_here |= lane == leader;
+  }
+  if (leader_here) f(key);
+}
+
 __global__ __launch_bounds__(256) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* rebal) {
   const uint32_t n = ctl->n_defer;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    const uint32_t j = defer[t];
-    const uint32_t X = xs[j], Y = ys[j];
-    uint32_t h = fmix32(X) & dmask;
-    for (;;) {
-      uint64_t* w = reinterpret_cast<uint64_t*>(&dir[h]);   // {meta, x}
-      uint64_t mx = ld_relaxed(w);
-      if (mx == 0) {
-        // create the row: reserve a directory place, then claim {meta,x} in one CAS
-        // (cheap pre-check: once the directory stands at its limit nobody touches the counter)
-        if (__hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= dir_limit) {
-          ctl->dir_full = 1;
-          break;
-        }
-        uint32_t r = atomicAdd(&ctl->dir_used, 1u);
-        if (r >= dir_limit) {
-          atomicSub(&ctl->dir_used, 1u);
-          ctl->dir_full = 1;
-          break;
-        }
-        uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
-        uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(w), 0ull,
-                                  (unsigned long long)want);
-        if (prev != 0) {
-          atomicSub(&ctl->dir_used, 1u);
-          continue;                       // somebody claimed this slot: look at it again
-        }
-        uint64_t u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), 1ull);
-        if (u >= arena_cap_units) { ctl->arena_oom = 1; break; }   // host guarantees this never fires
-        __hip_atomic_store(&dir[h].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      if ((uint32_t)(mx >> 32) == X) {
-        // row exists.  base==0: created a moment ago in this very launch -> empty, nothing to flag
-        uint32_t base = __hip_atomic_load(&dir[h].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t meta = (uint32_t)mx;
-        if (base != 0 && Y != 0) {
-          const uint32_t lg = meta_lg(meta);
-          const uint32_t mask = (1u << lg) - 1u;
-          const uint64_t* cells = row_cells(arena, base);
-          uint32_t pos = Y & mask;
-          bool absent = true;                     // also when the table has no empty cell left
-          for (uint32_t step = 0; step <= mask; step++) {
-            uint64_t c = cells[pos];
-            if (cell_key(c) == Y) { absent = false; break; }
-            if (c == 0) break;
-            pos = (pos + 1) & mask;
-          }
-          if (absent) meta = __hip_atomic_load(&dir[h].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (absent && !(meta & (META_GROW | META_REBAL))) {
-            uint32_t used = __hip_atomic_load(&dir[h].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lg >= BIG_LG) used += subs_sum(row_subs(arena, base, lg));
-            if (used > (mask + 1u) / 2u) {
-              uint32_t old = atomicOr(&dir[h].meta, META_GROW);
-              if (!(old & META_GROW)) {
-                uint32_t k = atomicAdd(&ctl->n_tasks, 1u);
-                tasks[k].dslot = h;
-                tasks[k].old_lg = lg;
-                tasks[k].old_base = base;
-                atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units),
-                          (unsigned long long)block_units(lg + 1));
-              }
-            } else if (lg >= BIG_LG) {
-              // room is left, but this op's sub-counter had used up its share: re-partition
-              uint32_t old = atomicOr(&dir[h].meta, META_REBAL);
-              if (!(old & META_REBAL)) rebal[atomicAdd(&ctl->n_rebal, 1u)] = h;
-            }
-          }
-        }
-        break;
-      }
-      h = (h + 1) & dmask;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t t_first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);      // wave-uniform loop bound
+  for (uint32_t t0 = t_first; t0 < n; t0 += stride) {
+    const uint32_t t = t0 + (threadIdx.x & 63u);
+    const bool live = t < n;
+    uint32_t X = 0, Y = 0;
+    if (live) {
+      const uint32_t j = defer[t];
+      X = xs[j];
+      Y = ys[j];
     }
+    // A. where does X live?  (read-only probe)
+    uint32_t h = fmix32(X) & dmask;
+    bool missing = false;
+    uint64_t mx = 0;
+    if (live) {
+      // PLAIN loads: a million deferred ops may all ask for the one hottest row, and L1-bypassing
+      // loads of a single word queue up at one L2 channel (5 ms measured).  A stale line can only
+      // show an empty slot where a row has just been created; the creation protocol below
+      // re-reads atomically, so that is harmless.  Keys of claimed slots never change.
+      for (;;) {
+        mx = *reinterpret_cast<const uint64_t*>(&dir[h]);           // {meta, x}
+        if (mx == 0) { missing = true; break; }
+        if ((uint32_t)(mx >> 32) == X) break;
+        h = (h + 1) & dmask;
+      }
+    }
+    // B. create missing rows, once per row id (src/smatrix.c:641-662)
+    per_distinct(missing, X, [&](uint32_t x0) {
+      uint32_t hh = fmix32(x0) & dmask;
+      for (;;) {
+        uint64_t* w = reinterpret_cast<uint64_t*>(&dir[hh]);
+        uint64_t cur = ld_relaxed(w);
+        if (cur == 0) {
+          // reserve a directory place, then claim {meta,x} in one CAS
+          // (cheap pre-check: once the directory stands at its limit nobody touches the counter)
+          if (__hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= dir_limit) {
+            ctl->dir_full = 1;
+            return;
+          }
+          uint32_t r = atomicAdd(&ctl->dir_used, 1u);
+          if (r >= dir_limit) {
+            atomicSub(&ctl->dir_used, 1u);
+            ctl->dir_full = 1;
+            return;
+          }
+          uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)x0 << 32);
+          uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(w), 0ull, (unsigned long long)want);
+          if (prev != 0) {
+            atomicSub(&ctl->dir_used, 1u);
+            continue;                       // somebody claimed this slot: look at it again
+          }
+          uint64_t u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), 1ull);
+          if (u >= arena_cap_units) { ctl->arena_oom = 1; return; }   // host guarantees this never fires
+          __hip_atomic_store(&dir[hh].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        if ((uint32_t)(cur >> 32) == x0) return;      // another wave created it meanwhile
+        hh = (hh + 1) & dmask;
+      }
+    });
+    // C. the row exists (base==0: created a moment ago in this very launch -> empty, nothing to flag):
+    //    is this op's key absent?
+    bool absent = false;
+    uint32_t base = 0, lg = 0;
+    if (live && !missing && Y != 0) {
+      base = dir[h].base;          // plain: 0 only for a row created in this very launch
+      if (base != 0) {
+        lg = meta_lg((uint32_t)mx);
+        const uint32_t mask = (1u << lg) - 1u;
+        const uint64_t* cells = row_cells(arena, base);
+        uint32_t pos = Y & mask;
+        absent = true;                              // also when the table has no empty cell left
+        for (uint32_t step = 0; step <= mask; step++) {
+          uint64_t c = cells[pos];
+          if (cell_key(c) == Y) { absent = false; break; }
+          if (c == 0) break;
+          pos = (pos + 1) & mask;
+        }
+      }
+    }
+    // D. once per row with an absent key: grow it iff it stands at the reference's threshold
+    //    (src/smatrix.c:346-348); a big row with room left only has its quotas re-partitioned
+    per_distinct(absent, h, [&](uint32_t h0) {
+      const uint32_t meta = __hip_atomic_load(&dir[h0].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (meta & (META_GROW | META_REBAL)) return;
+      const uint32_t lg0 = meta_lg(meta);
+      const uint32_t base0 = __hip_atomic_load(&dir[h0].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t used = __hip_atomic_load(&dir[h0].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lg0 >= BIG_LG) used += subs_sum(row_subs(arena, base0, lg0));
+      if (used > (1u << lg0) / 2u) {
+        uint32_t old = atomicOr(&dir[h0].meta, META_GROW);
+        if (!(old & META_GROW)) {
+          uint32_t k = atomicAdd(&ctl->n_tasks, 1u);
+          tasks[k].dslot = h0;
+          tasks[k].old_lg = lg0;
+          tasks[k].old_base = base0;
+          atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units),
+                    (unsigned long long)block_units(lg0 + 1));
+        }
+      } else if (lg0 >= BIG_LG) {
+        // room is left, but this op's sub-counter had used up its share: re-partition
+        uint32_t old = atomicOr(&dir[h0].meta, META_REBAL);
+        if (!(old & META_REBAL)) rebal[atomicAdd(&ctl->n_rebal, 1u)] = h0;
+      }
+    });
   }
 }
 
