@@ -506,40 +506,69 @@ __global__ __launch_bounds__(256) void k_prep(
         h = (h + 1) & dmask;
       }
     }
-    // B. create missing rows, once per row id (src/smatrix.c:641-662)
-    per_distinct(missing, X, [&](uint32_t x0) {
-      uint32_t hh = fmix32(x0) & dmask;
-      for (;;) {
-        uint64_t* w = reinterpret_cast<uint64_t*>(&dir[hh]);
-        uint64_t cur = ld_relaxed(w);
-        if (cur == 0) {
-          // reserve a directory place, then claim {meta,x} in one CAS
-          // (cheap pre-check: once the directory stands at its limit nobody touches the counter)
-          if (__hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= dir_limit) {
-            ctl->dir_full = 1;
-            return;
+    // B. create missing rows, once per row id (src/smatrix.c:641-662).  The directory counter and the
+    //    arena bump pointer are single words: every reservation is made ONCE PER WAVE for all of the
+    //    wave's new rows (a batch that creates 10^5 rows otherwise queues 2x10^5 returning atomics on
+    //    two addresses: 5 ms measured).
+    {
+      bool pending = false;
+      per_distinct(missing, X, [&](uint32_t) { pending = true; });
+      uint32_t hh = h;                                   // A stopped at the first empty slot it saw
+      const uint32_t lane = __lane_id();
+      while (__ballot(pending)) {
+        // B1. walk to the first slot that is empty or already holds X
+        bool at_empty = false;
+        if (pending) {
+          for (;;) {
+            uint64_t cur = ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh]));
+            if (cur == 0) { at_empty = true; break; }
+            if ((uint32_t)(cur >> 32) == X) { pending = false; break; }     // another wave created it
+            hh = (hh + 1) & dmask;
           }
-          uint32_t r = atomicAdd(&ctl->dir_used, 1u);
-          if (r >= dir_limit) {
-            atomicSub(&ctl->dir_used, 1u);
-            ctl->dir_full = 1;
-            return;
-          }
-          uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)x0 << 32);
-          uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(w), 0ull, (unsigned long long)want);
-          if (prev != 0) {
-            atomicSub(&ctl->dir_used, 1u);
-            continue;                       // somebody claimed this slot: look at it again
-          }
-          uint64_t u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), 1ull);
-          if (u >= arena_cap_units) { ctl->arena_oom = 1; return; }   // host guarantees this never fires
-          __hip_atomic_store(&dir[hh].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return;
         }
-        if ((uint32_t)(cur >> 32) == x0) return;      // another wave created it meanwhile
-        hh = (hh + 1) & dmask;
+        // B2. one directory reservation for all lanes that stand at an empty slot
+        const uint64_t em = __ballot(at_empty);
+        if (!em) continue;
+        const uint32_t lead = __ffsll((unsigned long long)em) - 1;
+        const uint32_t want_n = (uint32_t)__popcll(em);
+        uint32_t r0 = 0, added = 0;
+        if (lane == lead &&
+            __hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dir_limit) {
+          r0 = atomicAdd(&ctl->dir_used, want_n);        // may still land beyond the limit: given back below
+          added = 1;
+        }
+        r0 = __shfl(r0, lead);
+        added = __shfl(added, lead);
+        const uint32_t rank = (uint32_t)__popcll(em & ((1ull << lane) - 1));
+        bool reserved = at_empty && added && (uint64_t)r0 + rank < dir_limit;
+        // B3. claim {meta,x} in one CAS
+        bool won = false;
+        if (reserved) {
+          uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+          uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull,
+                                    (unsigned long long)want);
+          won = prev == 0;
+          if (!won && (uint32_t)(prev >> 32) == X) pending = false;         // lost to the same row: fine
+        }
+        if (at_empty && !reserved) { ctl->dir_full = 1; pending = false; }  // directory at its limit
+        // B4. give back what was reserved but not used; one arena reservation for the winners
+        const uint64_t wm = __ballot(won);
+        const uint32_t n_res = added ? want_n : 0u, n_won = (uint32_t)__popcll(wm);
+        uint64_t u0 = 0;
+        if (lane == lead) {
+          if (n_res > n_won) atomicSub(&ctl->dir_used, n_res - n_won);
+          if (n_won) u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)n_won);
+        }
+        u0 = __shfl(u0, lead);
+        if (won) {
+          const uint64_t u = u0 + (uint64_t)__popcll(wm & ((1ull << lane) - 1));
+          if (u >= arena_cap_units) ctl->arena_oom = 1;                      // host guarantees this never fires
+          else __hip_atomic_store(&dir[hh].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pending = false;
+        }
+        // (a lane that lost its slot to ANOTHER row id stays pending and walks on from there)
       }
-    });
+    }
     // C. the row exists (base==0: created a moment ago in this very launch -> empty, nothing to flag):
     //    is this op's key absent?
     bool absent = false;
