@@ -474,15 +474,20 @@ __device__ inline void per_distinct(bool want, uint32_t key, F f) {
   if (leader_here) f(key);
 }
 
-__global__ __launch_bounds__(256) void k_prep(
+constexpr uint32_t PREP_THREADS = 1024;
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* rebal) {
+  // block-scope scratch of the row-creation step
+  __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
+  __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
+  __shared__ unsigned long long l_u0;
   const uint32_t n = ctl->n_defer;
   const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t t_first = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);      // wave-uniform loop bound
-  for (uint32_t t0 = t_first; t0 < n; t0 += stride) {
-    const uint32_t t = t0 + (threadIdx.x & 63u);
+  for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += stride) {        // block-uniform trip count
+    const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
     uint32_t X = 0, Y = 0;
     if (live) {
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void k_prep(
     if (live) {
       // PLAIN loads: a million deferred ops may all ask for the one hottest row, and L1-bypassing
       // loads of a single word queue up at one L2 channel (5 ms measured).  A stale line can only
-      // show an empty slot where a row has just been created; the creation protocol below
+      // show an empty slot where a row has just been created; the creation step below
       // re-reads atomically, so that is harmless.  Keys of claimed slots never change.
       for (;;) {
         mx = *reinterpret_cast<const uint64_t*>(&dir[h]);           // {meta, x}
@@ -506,68 +511,72 @@ __global__ __launch_bounds__(256) void k_prep(
         h = (h + 1) & dmask;
       }
     }
-    // B. create missing rows, once per row id (src/smatrix.c:641-662).  The directory counter and the
-    //    arena bump pointer are single words: every reservation is made ONCE PER WAVE for all of the
-    //    wave's new rows (a batch that creates 10^5 rows otherwise queues 2x10^5 returning atomics on
-    //    two addresses: 5 ms measured).
-    {
-      bool pending = false;
-      per_distinct(missing, X, [&](uint32_t) { pending = true; });
-      uint32_t hh = h;                                   // A stopped at the first empty slot it saw
-      const uint32_t lane = __lane_id();
-      while (__ballot(pending)) {
-        // B1. walk to the first slot that is empty or already holds X
-        bool at_empty = false;
-        if (pending) {
-          for (;;) {
-            uint64_t cur = ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh]));
-            if (cur == 0) { at_empty = true; break; }
-            if ((uint32_t)(cur >> 32) == X) { pending = false; break; }     // another wave created it
-            hh = (hh + 1) & dmask;
-          }
+    // B. create missing rows, once per row id and BLOCK (src/smatrix.c:641-662).  The directory
+    //    counter and the arena bump pointer are single words: both are reserved once per block for
+    //    all of its new rows (per-op they queued 2x10^5 returning atomics on two addresses: 5 ms;
+    //    per wave still 3.7 ms on a batch that creates 10^5 rows).
+    if (__syncthreads_or(missing)) {
+      for (uint32_t i = threadIdx.x; i < 2 * PREP_THREADS; i += PREP_THREADS) l_set[i] = 0xFFFFFFFFu;
+      if (threadIdx.x < 4) l_cnt[threadIdx.x] = 0;
+      __syncthreads();
+      // B0. one lane per distinct row id (the id 0xFFFFFFFF cannot use the set: it always tries)
+      bool mine = missing;
+      if (missing && X != 0xFFFFFFFFu) {
+        uint32_t q = (X * 0x9E3779B1u) >> 21;            // 11 bits
+        for (;;) {
+          uint32_t prev = atomicCAS(&l_set[q], 0xFFFFFFFFu, X);
+          if (prev == 0xFFFFFFFFu) break;               // first of its id in this block
+          if (prev == X) { mine = false; break; }
+          q = (q + 1) & (2 * PREP_THREADS - 1);
         }
-        // B2. one directory reservation for all lanes that stand at an empty slot
-        const uint64_t em = __ballot(at_empty);
-        if (!em) continue;
-        const uint32_t lead = __ffsll((unsigned long long)em) - 1;
-        const uint32_t want_n = (uint32_t)__popcll(em);
-        uint32_t r0 = 0, added = 0;
-        if (lane == lead &&
-            __hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dir_limit) {
-          r0 = atomicAdd(&ctl->dir_used, want_n);        // may still land beyond the limit: given back below
-          added = 1;
-        }
-        r0 = __shfl(r0, lead);
-        added = __shfl(added, lead);
-        const uint32_t rank = (uint32_t)__popcll(em & ((1ull << lane) - 1));
-        bool reserved = at_empty && added && (uint64_t)r0 + rank < dir_limit;
-        // B3. claim {meta,x} in one CAS
-        bool won = false;
-        if (reserved) {
-          uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
-          uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull,
-                                    (unsigned long long)want);
-          won = prev == 0;
-          if (!won && (uint32_t)(prev >> 32) == X) pending = false;         // lost to the same row: fine
-        }
-        if (at_empty && !reserved) { ctl->dir_full = 1; pending = false; }  // directory at its limit
-        // B4. give back what was reserved but not used; one arena reservation for the winners
-        const uint64_t wm = __ballot(won);
-        const uint32_t n_res = added ? want_n : 0u, n_won = (uint32_t)__popcll(wm);
-        uint64_t u0 = 0;
-        if (lane == lead) {
-          if (n_res > n_won) atomicSub(&ctl->dir_used, n_res - n_won);
-          if (n_won) u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)n_won);
-        }
-        u0 = __shfl(u0, lead);
-        if (won) {
-          const uint64_t u = u0 + (uint64_t)__popcll(wm & ((1ull << lane) - 1));
-          if (u >= arena_cap_units) ctl->arena_oom = 1;                      // host guarantees this never fires
-          else __hip_atomic_store(&dir[hh].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          pending = false;
-        }
-        // (a lane that lost its slot to ANOTHER row id stays pending and walks on from there)
       }
+      // B1. walk (atomically) to the first slot that is empty or already holds X
+      bool at_empty = false;
+      uint32_t hh = h, rank = 0;
+      if (mine) {
+        for (;;) {
+          uint64_t cur = ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh]));
+          if (cur == 0) { at_empty = true; break; }
+          if ((uint32_t)(cur >> 32) == X) break;         // another block created it meanwhile
+          hh = (hh + 1) & dmask;
+        }
+        if (at_empty) rank = atomicAdd(&l_cnt[0], 1u);
+      }
+      __syncthreads();
+      // B2. one directory reservation for the block
+      if (threadIdx.x == 0 && l_cnt[0] &&
+          __hip_atomic_load(&ctl->dir_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dir_limit) {
+        l_cnt[2] = atomicAdd(&ctl->dir_used, l_cnt[0]);  // may still land beyond the limit: given back below
+        l_cnt[3] = 1;
+      }
+      __syncthreads();
+      // B3. claim {meta,x} in one CAS.  Losing the slot to ANOTHER row id is left to the next round
+      //     (the ops stay deferred), which keeps this step a single pass.
+      bool won = false;
+      uint32_t rank2 = 0;
+      if (at_empty) {
+        if (l_cnt[3] && (uint64_t)l_cnt[2] + rank < dir_limit) {
+          uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+          won = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull, (unsigned long long)want) == 0;
+          if (won) rank2 = atomicAdd(&l_cnt[1], 1u);
+        } else {
+          ctl->dir_full = 1;                             // directory at its limit
+        }
+      }
+      __syncthreads();
+      // B4. give back what was reserved but not used; one arena reservation for the winners
+      if (threadIdx.x == 0) {
+        const uint32_t n_res = l_cnt[3] ? l_cnt[0] : 0u, n_won = l_cnt[1];
+        if (n_res > n_won) atomicSub(&ctl->dir_used, n_res - n_won);
+        if (n_won) l_u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)n_won);
+      }
+      __syncthreads();
+      if (won) {
+        const uint64_t u = l_u0 + rank2;
+        if (u >= arena_cap_units) ctl->arena_oom = 1;                        // host guarantees this never fires
+        else __hip_atomic_store(&dir[hh].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();                                   // l_cnt / l_set are reused by the next trip
     }
     // C. the row exists (base==0: created a moment ago in this very launch -> empty, nothing to flag):
     //    is this op's key absent?

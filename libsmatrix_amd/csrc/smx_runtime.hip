@@ -338,7 +338,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
-    hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), 2048)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                        (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->rebal.p);
     HIP_OK(hipGetLastError());
