@@ -163,9 +163,26 @@ __device__ inline void list_push(uint32_t* counter, uint32_t* list, uint32_t idx
 //
 //   idx   : nullptr for round 0 (op i = thread i), else the deferred op list
 //   cellp : unused here (set duplicates are resolved after the rounds, k_set_locate)
+// one insert ticket from a sub-counter, or nullptr when its share of the room is used up
+__device__ inline uint32_t* sub_ticket(SubCtr* sc) {
+  const uint2 cq = *reinterpret_cast<const uint2*>(sc);      // {cnt, quota}; quota is stable in op kernels
+  if (cq.x >= cq.y) return nullptr;
+  if (atomicAdd(&sc->cnt, 1u) >= cq.y) { atomicSub(&sc->cnt, 1u); return nullptr; }
+  return &sc->cnt;
+}
+// Own share exhausted: three more at stride SUBS/4.  With >= SUBS/4 tickets of room left some share on
+// that stride still has one, so a nearly full row does not bounce its ops through re-partition rounds.
+// Only the small-batch kernel (k_apply: retry rounds, scalar calls) is PATIENT; in the aggregating
+// kernel the extra code cost 0.4 ms per 2^24-op batch.
+__device__ inline uint32_t* sub_ticket_elsewhere(SubCtr* subs, uint32_t k0) {
+  for (uint32_t a = 1; a < 4; a++)
+    if (uint32_t* t = sub_ticket(subs + ((k0 + a * (SUBS / 4u)) & (SUBS - 1u)))) return t;
+  return nullptr;
+}
+
 // The per-op body: returns the op's result (new value for writers); *deferred is set when a
 // structure change must happen first.
-template <int OP>
+template <int OP, bool PATIENT = false>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
                                      uint32_t Y, uint32_t V, bool* deferred) {
   uint32_t result = 0;
@@ -201,15 +218,11 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
           // big row: take the ticket from one of the sub-counters (its quota is a share of the room)
           // (spread by lane as well: a handful of retried ops all sit in one wave and must not
           //  queue on the single share of one sub-counter)
-          SubCtr* sc = row_subs(arena, s.z, lg) + ((blockIdx.x * 5u + threadIdx.x) & (SUBS - 1u));
-          const uint2 cq = *reinterpret_cast<const uint2*>(sc);      // {cnt, quota}; quota is stable here
-          if (cq.x >= cq.y) { *deferred = true; return 0; }
-          ticket = &sc->cnt;
-          if (atomicAdd(ticket, 1u) >= cq.y) {
-            atomicSub(ticket, 1u);
-            *deferred = true;
-            return 0;
-          }
+          SubCtr* subs = row_subs(arena, s.z, lg);
+          const uint32_t k0 = (blockIdx.x * 5u + threadIdx.x) & (SUBS - 1u);
+          ticket = sub_ticket(subs + k0);
+          if (PATIENT && !ticket) ticket = sub_ticket_elsewhere(subs, k0);
+          if (!ticket) { *deferred = true; return 0; }
         } else {
           if (s.w > (mask + 1u) / 2u) { *deferred = true; return 0; }
           ticket = &d->used;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(256) void k_apply(
   bool deferred = false;
   if (live) {
     j = idx ? idx[t] : t;
-    uint32_t r = apply_one<OP>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
+    uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
     if (!deferred) out[j] = r;
   }
   if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
@@ -312,8 +325,13 @@ constexpr uint32_t AGG_THREADS = SMX_AGG_THREADS;  // lanes per workgroup
 constexpr uint32_t AGG_TILE = AGG_THREADS * AGG_OPT;   // ops per workgroup
 constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/2)
 
+// SGPR budget: gfx950 admits 8 waves per SIMD only up to 80 SGPRs (MI355X_MICROARCH.md, residency);
+// at 82 a CU holds ONE 1024-lane workgroup instead of two and the kernel takes 1.84 ms instead of 1.49.
+#ifndef SMX_AGG_SGPRS
+#define SMX_AGG_SGPRS 80
+#endif
 template <int OP>
-__global__ __launch_bounds__(AGG_THREADS) void k_apply_agg(
+__global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_apply_agg(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
