@@ -194,6 +194,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # informative extra (not `value`): the same step on the finished table -- every incr is a hit
+    steady = None
+    if not sharded:
+        fence()
+        t1 = time.perf_counter()
+        for s in range(total_steps - 4, total_steps):
+            step(s)
+        fence()
+        steady = {"steps": 4, "ms_per_step": (time.perf_counter() - t1) / 4 * 1e3,
+                  "Mops_per_s": 2 * B * 4 / (time.perf_counter() - t1) / 1e6,
+                  "note": "last 4 batches replayed on the 100.4M-nnz table: no inserts, no growth"}
+
     # parity spot-check inside the bench: the last get batch must equal the last incr returns' per-key max
     ok = bool((out_g >= 1).all().item())
 
@@ -236,6 +248,8 @@ def main():
                 res["roofline"]["traffic_source"] = res["roofline_get"]["traffic_source"] = "profiles/r01_pmc_summary.txt"
         except Exception:
             pass
+        if steady:
+            res["steady_state_all_hits"] = steady
         res["table"] = {k: st[k] for k in ("rows", "dir_slots", "arena_units", "arena_mapped", "batches",
                                            "rounds", "deferred_ops", "rows_grown", "dir_grown")}
         if world == 1:

@@ -351,9 +351,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       struct timespec ts;
       clock_gettime(CLOCK_MONOTONIC, &ts);
       const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-      fprintf(stderr, "[smatrix] batch %llu round %u (+%.3f ms): ops=%u deferred=%u grow=%u rebal=%u dir_full=%u rows=%u\n",
+      fprintf(stderr, "[smatrix] batch %llu round %u (+%.3f ms): ops=%u deferred=%u grow=%u (%llu units) rebal=%u dir_full=%u rows=%u\n",
               (unsigned long long)m->st.batches, round, t_prev ? now - t_prev : 0.0, cur_n, m->h_ctl->n_defer,
-              m->h_ctl->n_tasks, m->h_ctl->n_rebal, m->h_ctl->dir_full, m->h_ctl->dir_used);
+              m->h_ctl->n_tasks, (unsigned long long)m->h_ctl->grow_units, m->h_ctl->n_rebal, m->h_ctl->dir_full,
+              m->h_ctl->dir_used);
       t_prev = now;
     }
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
