@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -168,10 +169,20 @@ struct DevBuf {
   }
 };
 
+struct ScalarReq {
+  int op;
+  uint32_t x, y, v, result;
+  bool done;
+};
+
 struct Matrix {
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
+  std::mutex qmu;                       // scalar-call combining (see scalar_op)
+  std::condition_variable qcv;
+  std::vector<ScalarReq*> queue;
+  bool combining = false;
 
   Ctl* d_ctl = nullptr;
   Ctl* h_ctl = nullptr;        // pinned
@@ -671,10 +682,8 @@ int smatrix_cf_neighbors_batch(smatrix_t* self, size_t n, const uint32_t* items,
 }
 
 // ---- the reference's scalar entry points: one-op batches --------------------------
-static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint32_t v) {
-  Matrix* m = M(self);
-  set_device(m);
-  std::lock_guard<std::mutex> g(m->mu);
+// One scalar op with the matrix lock held.
+static uint32_t scalar_one_locked(smatrix_t* self, Matrix* m, int op, uint32_t x, uint32_t y, uint32_t v) {
   hipStream_t s = m->stream;
   // fast path: one launch, result written by the kernel into pinned host memory, one sync.
   // (set keeps its value write inside apply_one; a one-op batch has no duplicates to resolve)
@@ -700,6 +709,66 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
   HIP_OK(hipMemcpyAsync(m->h_small + 3, m->d_small + 3, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   return m->h_small[3];
+}
+
+// The reference's scalar calls are thread-safe and callers (JVM threads, src/smatrix_jni.c) issue them
+// concurrently.  A device round trip per call would serialise them at ~15 us each, so concurrent
+// callers are COMBINED: every caller queues its op; whoever finds no combiner active becomes it, takes
+// everything queued so far and runs it as one batch per op kind (any order among concurrent calls is
+// a legal serialisation; each thread's own calls stay ordered because a thread has one call in flight).
+// A lone caller pays nothing extra: a queue of one goes down the one-launch fast path.
+static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint32_t v) {
+  Matrix* m = M(self);
+  ScalarReq req{op, x, y, v, 0, false};
+  std::unique_lock<std::mutex> ql(m->qmu);
+  m->queue.push_back(&req);
+  if (m->combining) {
+    m->qcv.wait(ql, [&] { return req.done || !m->combining; });
+    if (req.done) return req.result;
+  }
+  // become the combiner
+  m->combining = true;
+  std::vector<ScalarReq*> work;
+  while (!m->queue.empty()) {
+    work.clear();
+    work.swap(m->queue);
+    ql.unlock();
+    {
+      set_device(m);
+      std::lock_guard<std::mutex> g(m->mu);
+      if (work.size() == 1) {
+        ScalarReq* r = work[0];
+        r->result = scalar_one_locked(self, m, r->op, r->x, r->y, r->v);
+      } else {
+        hipStream_t s = m->stream;
+        for (int kind = 0; kind < 4; kind++) {
+          size_t k = 0;
+          for (ScalarReq* r : work) k += r->op == kind;
+          if (!k) continue;
+          std::vector<uint32_t> hx(k), hy(k), hv(k), ho(k);
+          size_t i = 0;
+          for (ScalarReq* r : work)
+            if (r->op == kind) { hx[i] = r->x; hy[i] = r->y; hv[i] = r->v; i++; }
+          m->sx.need(k); m->sy.need(k); m->sv.need(k); m->so.need(k);
+          HIP_OK(hipMemcpyAsync(m->sx.p, hx.data(), k * 4, hipMemcpyHostToDevice, s));
+          HIP_OK(hipMemcpyAsync(m->sy.p, hy.data(), k * 4, hipMemcpyHostToDevice, s));
+          HIP_OK(hipMemcpyAsync(m->sv.p, hv.data(), k * 4, hipMemcpyHostToDevice, s));
+          apply_dev_locked(self, kind, k, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);
+          HIP_OK(hipMemcpyAsync(ho.data(), m->so.p, k * 4, hipMemcpyDeviceToHost, s));
+          HIP_OK(hipStreamSynchronize(s));
+          i = 0;
+          for (ScalarReq* r : work)
+            if (r->op == kind) r->result = ho[i++];
+        }
+      }
+    }
+    ql.lock();
+    for (ScalarReq* r : work) r->done = true;
+    m->qcv.notify_all();
+  }
+  m->combining = false;
+  m->qcv.notify_all();
+  return req.result;
 }
 
 uint32_t smatrix_get(smatrix_t* self, uint32_t x, uint32_t y) { return scalar_op(self, OP_GET, x, y, 0); }
