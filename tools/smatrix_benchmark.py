@@ -7,13 +7,12 @@ Restates the stock workload exactly: thread t uses o = 42+t and runs, `user1 = t
 for n<23, i<22: incr(n+o, i+o, 1); incr(i+o, n+o, 1)   (src/smatrix_benchmark.c:29-46; get: :48-65),
 printing the reference's table (:134-138) -- one row of T=1..32 per backend:
 
-  reference  the compiled reference via oracle/_ref, real pthreads-equivalent (one C call per
-             thread; timing includes thread create/join like :109-122)   [checker library]
-  hip-scalar the drop-in scalar ABI, T host threads on one handle (one device round trip per op)
   hip-batch  the same op multiset as ONE batched call per thread count
+  hip-scalar the drop-in scalar ABI, T host threads on one handle (one device round trip per op)
 
 The batched line is what the GPU path is for; the scalar line documents the cost of the
-one-op-per-call ABI."""
+one-op-per-call ABI.  The reference's own row of the table is printed by
+tests/stock_benchmark_reference.py (the compiled reference is checker code and stays under tests/)."""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -44,12 +43,9 @@ def main():
     Ts = [only_t] if only_t else [1, 2, 4, 8, 16, 32]
     import libsmatrix_amd
     from libsmatrix_amd import SparseMatrix
-    from oracle import oracle as O
-    backends = []
-    if O.have_reference():
-        backends.append(("reference", lambda: O.Reference(fname)))
-    if libsmatrix_amd.device_available():
-        backends += [("hip-batch", lambda: SparseMatrix(fname)), ("hip-scalar", lambda: SparseMatrix(fname))]
+    if not libsmatrix_amd.device_available():
+        sys.exit("no HIP device (the product has no CPU path)")
+    backends = [("hip-batch", lambda: SparseMatrix(fname)), ("hip-scalar", lambda: SparseMatrix(fname))]
     for op in (["incr", "get"] if test == "full" else [test]):
         print("TEST: %s" % ("1 million x mixed " + op))
         print("-" * 63)
@@ -59,12 +55,7 @@ def main():
             cells = []
             for T in Ts:
                 user1 = max(times // T, 1)
-                if name == "reference":
-                    def fn(t):
-                        x, y = pattern(t, user1)
-                        m.apply(O.OP_INCR if op == "incr" else O.OP_GET, x, y, np.ones_like(x))
-                    cells.append("%.1fms" % measure(fn, T))
-                elif name == "hip-batch":
+                if name == "hip-batch":
                     xs, ys = zip(*(pattern(t, user1) for t in range(T)))
                     x, y = np.concatenate(xs), np.concatenate(ys)
                     t0 = time.perf_counter()
