@@ -43,6 +43,10 @@ class HipShard:
             self.m.apply_batch_dev(op, n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None,
                                    out.data_ptr(), _stream())
 
+    def rowlen(self, x, out):
+        if x.numel():
+            self.m.rowlen_batch_dev(x.numel(), x.data_ptr(), out.data_ptr(), _stream())
+
     def close(self):
         self.m.close()
 
@@ -150,6 +154,24 @@ class ShardedMatrix:
         dist.all_to_all_single(back, outr, counts, rcounts, group=self.group)
         self.part.gather(back, perm, out)
         self.exchanged_ops += nr
+        return out
+
+    def rowlen_dev(self, xs, out):
+        """rowlen of arbitrary rows: routed to the owners like an op batch (rows are shard-local, so a
+        scan of a rank's OWN rows -- local.rowlen_batch / local.getrow_batch -- needs no exchange at all).
+        COLLECTIVE."""
+        counts, perm, xo, _, _ = self.part.partition(xs, xs, None, self.world)
+        send = torch.tensor(counts, dtype=torch.int64, device=xs.device)
+        recv = torch.empty(self.world, dtype=torch.int64, device=xs.device)
+        dist.all_to_all_single(recv, send, group=self.group)
+        rcounts = [int(c) for c in recv.tolist()]
+        xr = torch.empty(sum(rcounts), dtype=xs.dtype, device=xs.device)
+        dist.all_to_all_single(xr, xo, rcounts, counts, group=self.group)
+        lr = torch.empty_like(xr)
+        self.shard.rowlen(xr, lr)
+        back = torch.empty(xs.numel(), dtype=xs.dtype, device=xs.device)
+        dist.all_to_all_single(back, lr, counts, rcounts, group=self.group)
+        self.part.gather(back, perm, out)
         return out
 
     # ---- split-phase form: lets the exchange of one batch overlap the op kernels of another -------

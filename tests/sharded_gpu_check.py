@@ -41,5 +41,8 @@ for s in range(S):
     b = b[torch.argsort(b[:, 1], stable=True)]; b = b[torch.argsort(b[:, 0], stable=True)]
     assert torch.equal(a, b), "incr returns mismatch at step %d" % s
 assert direct.stats()["rows"] == sm.local.stats()["rows"]
+q = xs[0][:100000].contiguous(); l1 = torch.empty_like(q); l2 = torch.empty_like(q)
+sm.rowlen_dev(q, l1); direct.rowlen_batch_dev(q.numel(), q.data_ptr(), l2.data_ptr(), st); torch.cuda.synchronize()
+assert torch.equal(l1, l2)
 print("SHARDED_PIPELINE_OK")
 sm.close(); direct.close(); dist.destroy_process_group()

@@ -62,6 +62,10 @@ class OracleShard:
                          v.numpy().view(np.uint32) if v is not None else None)
         out.copy_(torch.from_numpy(r.view(np.int32)))
 
+    def rowlen(self, x, out):
+        xs = x.numpy().view(np.uint32)
+        out.copy_(torch.tensor([self.m.rowlen(int(v)) for v in xs], dtype=torch.int64).to(torch.int32))
+
     def close(self):
         self.m.close()
 
@@ -115,6 +119,11 @@ def main():
     uk, inv = np.unique(key, return_inverse=True)
     mine = np.zeros(uk.size, np.uint32); np.maximum.at(mine, inv, out_i.numpy().view(np.uint32))
     assert (mine <= ref.apply(O.OP_GET, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32))).all()
+    # rowlen of arbitrary rows, routed to the owners
+    q = torch.from_numpy(np.unique(x)[:3000].view(np.int32).copy())
+    lens = torch.empty_like(q)
+    sm.rowlen_dev(q, lens)
+    assert lens.tolist() == [ref.rowlen(int(v)) for v in q.numpy().view(np.uint32)]
     # every row lives on exactly its owner, with the same length as in the single matrix
     rows = sm.shard.m.list_rows()
     assert (shard_of_np(rows, world) == rank).all(), "a row landed on the wrong shard"
