@@ -111,6 +111,17 @@ class ShardedMatrix:
         self.part = partitioner if partitioner is not None else HipPartitioner(device)
         self.exchanged_ops = 0
         self.packed = os.environ.get("SMATRIX_SHARD_PACKED", "1") != "0"   # one collective per op batch
+        self.host_staged = os.environ.get("SMATRIX_SHARD_HOST_STAGED", "0") == "1"
+
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        """all_to_all_single; with SMATRIX_SHARD_HOST_STAGED=1 the payload is staged through host
+        memory (lets two ranks share ONE GPU over gloo -- test rigs only, RCCL refuses duplicate GPUs)."""
+        if self.host_staged and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     @property
     def local(self):
@@ -131,27 +142,27 @@ class ShardedMatrix:
             counts, perm, xo, yo, vo = self.part.partition(x, y, vv, self.world)
         send = torch.tensor(counts, dtype=torch.int64, device=x.device)
         recv = torch.empty(self.world, dtype=torch.int64, device=x.device)
-        dist.all_to_all_single(recv, send, group=self.group)
+        self._a2a(recv, send)
         rcounts = [int(c) for c in recv.tolist()]
         nr = sum(rcounts)
         if packed_path:
             # one collective for the whole op record (splits count rows of the [n, w] tensor)
             pr = torch.empty((nr, po.shape[1]), dtype=x.dtype, device=x.device)
-            dist.all_to_all_single(pr, po, rcounts, counts, group=self.group)
+            self._a2a(pr, po, rcounts, counts)
             xr, yr, vr = self.part.unpack(pr)
         else:
             xr = torch.empty(nr, dtype=x.dtype, device=x.device)
             yr = torch.empty(nr, dtype=x.dtype, device=x.device)
-            dist.all_to_all_single(xr, xo, rcounts, counts, group=self.group)
-            dist.all_to_all_single(yr, yo, rcounts, counts, group=self.group)
+            self._a2a(xr, xo, rcounts, counts)
+            self._a2a(yr, yo, rcounts, counts)
             vr = None
             if op != OP_GET:
                 vr = torch.empty(nr, dtype=x.dtype, device=x.device)
-                dist.all_to_all_single(vr, vo, rcounts, counts, group=self.group)
+                self._a2a(vr, vo, rcounts, counts)
         outr = torch.empty(nr, dtype=x.dtype, device=x.device)
         self.shard.apply(op, xr, yr, vr, outr)
         back = torch.empty(x.numel(), dtype=x.dtype, device=x.device)
-        dist.all_to_all_single(back, outr, counts, rcounts, group=self.group)
+        self._a2a(back, outr, counts, rcounts)
         self.part.gather(back, perm, out)
         self.exchanged_ops += nr
         return out
@@ -163,14 +174,14 @@ class ShardedMatrix:
         counts, perm, xo, _, _ = self.part.partition(xs, xs, None, self.world)
         send = torch.tensor(counts, dtype=torch.int64, device=xs.device)
         recv = torch.empty(self.world, dtype=torch.int64, device=xs.device)
-        dist.all_to_all_single(recv, send, group=self.group)
+        self._a2a(recv, send)
         rcounts = [int(c) for c in recv.tolist()]
         xr = torch.empty(sum(rcounts), dtype=xs.dtype, device=xs.device)
-        dist.all_to_all_single(xr, xo, rcounts, counts, group=self.group)
+        self._a2a(xr, xo, rcounts, counts)
         lr = torch.empty_like(xr)
         self.shard.rowlen(xr, lr)
         back = torch.empty(xs.numel(), dtype=xs.dtype, device=xs.device)
-        dist.all_to_all_single(back, lr, counts, rcounts, group=self.group)
+        self._a2a(back, lr, counts, rcounts)
         self.part.gather(back, perm, out)
         return out
 
@@ -211,23 +222,23 @@ class ShardedMatrix:
                 h.counts, h.perm, xo, yo, vo = self.part.partition(x, y, vv, self.world)
             send = torch.tensor(h.counts, dtype=torch.int64, device=x.device)
             recv = torch.empty(self.world, dtype=torch.int64, device=x.device)
-            dist.all_to_all_single(recv, send, group=self.group)
+            self._a2a(recv, send)
             h.rcounts = [int(c) for c in recv.tolist()]
             nr = sum(h.rcounts)
             if packed_path:
                 pr = torch.empty((nr, po.shape[1]), dtype=x.dtype, device=x.device)
-                dist.all_to_all_single(pr, po, h.rcounts, h.counts, group=self.group)
+                self._a2a(pr, po, h.rcounts, h.counts)
                 h.xr, h.yr, h.vr = self.part.unpack(pr)
                 h.keep = (x, y, v, po, pr)
             else:
                 h.xr = torch.empty(nr, dtype=x.dtype, device=x.device)
                 h.yr = torch.empty(nr, dtype=x.dtype, device=x.device)
-                dist.all_to_all_single(h.xr, xo, h.rcounts, h.counts, group=self.group)
-                dist.all_to_all_single(h.yr, yo, h.rcounts, h.counts, group=self.group)
+                self._a2a(h.xr, xo, h.rcounts, h.counts)
+                self._a2a(h.yr, yo, h.rcounts, h.counts)
                 h.vr = None
                 if vv is not None:
                     h.vr = torch.empty(nr, dtype=x.dtype, device=x.device)
-                    dist.all_to_all_single(h.vr, vo, h.rcounts, h.counts, group=self.group)
+                    self._a2a(h.vr, vo, h.rcounts, h.counts)
                 h.keep = (x, y, v, xo, yo, vo)
             h.outr = torch.empty(nr, dtype=x.dtype, device=x.device)
             h.ev_routed = comm.record_event() if comm is not None else None
@@ -252,7 +263,7 @@ class ShardedMatrix:
                 comm.wait_event(h.ev_applied)
                 out.record_stream(comm)
             back = torch.empty(h.n, dtype=out.dtype, device=out.device)
-            dist.all_to_all_single(back, h.outr, h.counts, h.rcounts, group=self.group)
+            self._a2a(back, h.outr, h.counts, h.rcounts)
             self.part.gather(back, h.perm, out)
             h.ev_done = comm.record_event() if comm is not None else None
             h.keep = h.keep + (back,)

@@ -1,0 +1,60 @@
+"""Run by tests/test_gpu_parity.py::test_sharded_two_ranks_one_gpu under torch.distributed.run (2 ranks, gloo,
+BOTH on cuda:0, payload staged through the host: SMATRIX_SHARD_HOST_STAGED=1).  The real HIP partitioner,
+the real HIP shards and the pipelined split-phase routing with world_size 2, checked against a single
+un-sharded HIP matrix fed with the ops of both ranks."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR, _lib
+from libsmatrix_amd.sharded import ShardedMatrix
+
+B, S = 1 << 18, 4
+gen = Stream("zipf", 999 + rank, 100000, 1.1, 1)
+xs = torch.empty((S, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
+st = torch.cuda.current_stream().cuda_stream
+for s in range(S):
+    gen.fill_device(s * B, B, xs[s].data_ptr(), ys[s].data_ptr(), st)
+ones = torch.ones(B, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+sm, direct = ShardedMatrix(), SparseMatrix()
+pending = {}
+for s in range(S):
+    oi = torch.full((B,), -7, dtype=torch.int32, device=dev); og = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    h_i = pending.pop(s, None) or sm.route(OP_INCR, xs[s], ys[s], ones)
+    h_g = sm.route(OP_GET, xs[s], ys[s])
+    sm.apply_routed(h_i); sm.finish(h_i, oi)
+    if s + 1 < S:
+        pending[s + 1] = sm.route(OP_INCR, xs[s + 1], ys[s + 1], ones)
+    sm.apply_routed(h_g); sm.finish(h_g, og)
+    sm.wait(h_i); sm.wait(h_g)
+    torch.cuda.synchronize()
+    # the un-sharded matrix sees the step's ops of ALL ranks, then this rank's gets
+    allx = [torch.empty(B, dtype=torch.int32) for _ in range(world)]; ally = [torch.empty(B, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(allx, xs[s].cpu()); dist.all_gather(ally, ys[s].cpu())
+    for r in range(world):
+        ax, ay = allx[r].to(dev), ally[r].to(dev); tmp = torch.empty_like(ax)
+        direct.apply_batch_dev(OP_INCR, B, ax.data_ptr(), ay.data_ptr(), ones.data_ptr(), tmp.data_ptr(), st)
+    dg = torch.empty(B, dtype=torch.int32, device=dev)
+    direct.apply_batch_dev(OP_GET, B, xs[s].data_ptr(), ys[s].data_ptr(), None, dg.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(og, dg), "rank %d step %d: sharded get != un-sharded get" % (rank, s)
+    assert int((oi <= og).all()), "an incr return exceeds the value the following get saw"
+lib = _lib.load()
+rows = torch.unique(torch.cat([xs.reshape(-1)]))[:20000]
+owners = torch.tensor([lib.smatrix_shard_of(int(v) & 0xFFFFFFFF, world) for v in rows[:2000].tolist()])
+mine = rows[:2000][owners == rank]
+if mine.numel():
+    l = torch.empty(mine.numel(), dtype=torch.int32, device=dev)
+    sm.local.rowlen_batch_dev(mine.numel(), mine.contiguous().data_ptr(), l.data_ptr(), st); torch.cuda.synchronize()
+    assert int((l > 0).all()), "an owned row is missing from the local shard"
+tot = torch.tensor([sm.local.stats()["rows"]]); dist.all_reduce(tot)
+assert int(tot) == direct.stats()["rows"], (int(tot), direct.stats()["rows"])
+dist.barrier()
+if rank == 0:
+    print("SHARDED_2RANK_OK rows=%d" % int(tot))
+sm.close(); direct.close(); dist.destroy_process_group()

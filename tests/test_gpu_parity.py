@@ -550,3 +550,14 @@ def test_hypothesis_small_sequences_vs_oracle(G, oracle_mod):
             g.close(); o.close()
 
     run()
+
+
+def test_sharded_two_ranks_one_gpu():
+    """world_size 2 on ONE GPU (gloo, payload staged through the host): real HIP partitioner + shards +
+    pipelined routing against an un-sharded HIP matrix -- the closest a 1-GPU box gets to the N>1 path"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29599", os.path.join(root, "tests", "sharded_gpu_2rank.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0 and "SHARDED_2RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
