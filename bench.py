@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-sample-lg", type=int, default=26)
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events (A/B of the overhead)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded path: one blocking apply_dev per op batch")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for test rigs)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="test rig: every rank uses cuda:0 and the exchange is staged through the host (gloo)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="route through ShardedMatrix even with one rank (exercises the exchange path)")
     args = ap.parse_args()
@@ -120,6 +123,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with python -m torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.single_device:
+        local = 0
+        os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sharded = world > 1 or args.force_sharded
@@ -127,7 +133,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # single process, --force-sharded
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
     B = 1 << args.batch_lg
@@ -190,7 +199,7 @@ def main():
     st = local_m.stats()
     local_m.profile(False)
     if sharded:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

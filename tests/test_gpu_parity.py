@@ -561,3 +561,20 @@ def test_sharded_two_ranks_one_gpu():
            "--master-addr", "127.0.0.1", "--master-port", "29599", os.path.join(root, "tests", "sharded_gpu_2rank.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert p.returncode == 0 and "SHARDED_2RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_bench_launch_contract_two_ranks():
+    """the driver's N>1 launch line (torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE from the env, ONE JSON
+    line from rank 0) on the 1-GPU rig: both ranks on cuda:0, gloo, host-staged exchange"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-lg", "18", "--backend", "gloo", "--single-device"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak" and res["sanity_all_gets_positive"]
+    assert res["value"] > 0 and "roofline" in res
