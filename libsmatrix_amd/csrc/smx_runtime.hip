@@ -114,9 +114,14 @@ struct Arena {
       ad.location.type = hipMemLocationTypeDevice;
       ad.location.id = device;
       ad.flags = hipMemAccessFlagsProtReadWrite;
-      // ROCm 7.2: access must be set from the start of the reservation (a sub-range
-      // starting at the new chunk returns hipErrorInvalidValue; tools/probe/vmm.cpp)
-      HIP_OK(hipMemSetAccess(base, mapped + add, &ad, 1));
+      // Access for the new chunk only where the runtime takes a sub-range (the HIP 7.0 runtime bundled
+      // with PyTorch does; there the whole-range form costs ~8 ms per mapped GB: 30-60 ms per growth of a
+      // 5-7 GB arena).  ROCm 7.2's own runtime rejects a sub-range with hipErrorInvalidValue
+      // (tools/probe/vmm.cpp) and does the whole range in microseconds -- so: try, then fall back.
+      if (hipMemSetAccess(base + mapped, add, &ad, 1) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_OK(hipMemSetAccess(base, mapped + add, &ad, 1));
+      }
       HIP_OK(hipMemsetAsync(base + mapped, 0, add, st));
       chunks.push_back({h, add});
       mapped += add;
@@ -233,6 +238,18 @@ void ctl_read(Matrix* m, hipStream_t s) {
 void ensure_arena_free(Matrix* m, uint64_t units, hipStream_t s) {
   uint64_t need = (m->arena_next + units) * UNIT_BYTES;
   if (need <= m->arena.mapped) return;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  struct Report {
+    Matrix* m; struct timespec* t0; struct timespec* t1; hipStream_t s;
+    ~Report() {
+      if (!m->trace_rounds) return;
+      (void)hipStreamSynchronize(s);
+      clock_gettime(CLOCK_MONOTONIC, t1);
+      fprintf(stderr, "[smatrix]   arena grown to %.2f GB in %.3f ms\n", m->arena.mapped / 1e9,
+              (t1->tv_sec - t0->tv_sec) * 1e3 + (t1->tv_nsec - t0->tv_nsec) * 1e-6);
+    }
+  } report{m, &t0, &t1, s};
   // grow geometrically so that mapping calls stay rare
   uint64_t target = std::max<uint64_t>(need, m->arena.mapped + m->arena.mapped / 2);
   if (m->arena.vmm) target = std::min<uint64_t>(std::max<uint64_t>(need, target), m->arena.reserved);
@@ -324,6 +341,17 @@ void grow_rows(Matrix* m, hipStream_t s) {
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir, m->arena.base);
   HIP_OK(hipGetLastError());
+  if (m->trace_rounds && nt > 1000) {      // who grows?  (cells moved, by log2 of the old row size)
+    std::vector<GrowTask> ht(nt);
+    HIP_OK(hipMemcpyAsync(ht.data(), m->tasks.p, (size_t)nt * sizeof(GrowTask), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    uint64_t cnt[32] = {0};
+    for (const GrowTask& k : ht) cnt[k.old_lg & 31]++;
+    fprintf(stderr, "[smatrix]   growth by old size:");
+    for (int lg = 4; lg < 32; lg++)
+      if (cnt[lg]) fprintf(stderr, " 2^%d x%llu (%.1fM cells)", lg, (unsigned long long)cnt[lg], cnt[lg] * (double)(1ull << lg) / 1e6);
+    fprintf(stderr, "\n");
+  }
   m->arena_next += gu;   // exact: plan hands out precisely grow_units
   m->st.rows_grown += nt;
 }
