@@ -34,10 +34,6 @@ for s in range(NB):
 run(OP_INCR, xs[NB - 1], ys[NB - 1], "zipf incr: repeat last batch (all hits)")
 run(OP_INCR, xs[0], ys[0], "zipf incr: repeat batch 0 (all hits)")
 run(OP_GET, xs[NB - 1], ys[NB - 1], "zipf get last batch")
-import ctypes
-from libsmatrix_amd import _lib as _L
-if hasattr(_L.load(), "smatrix_debug_flag") and len(sys.argv) > 2:
-    _L.load().smatrix_debug_flag(int(sys.argv[2])); print("debug flag", sys.argv[2])
 run(OP_INCR, xs[NB], ys[NB], "zipf incr next new batch")
 run(OP_INCR, ux, uy, "uniform 4M x 4M incr (all new rows+cells)")
 run(OP_INCR, ux, uy, "uniform incr repeat (all hits, no dups)")
