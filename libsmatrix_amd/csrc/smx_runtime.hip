@@ -362,8 +362,6 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   if (n == 0) return;
   m->defer[0].need(n);
   m->defer[1].need(n);
-  m->tasks.need(n);
-  m->rebal.need(n);
   if (op == OP_SET) m->cellp.need(n);
   m->st.batches++;
 
@@ -375,6 +373,9 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     const uint32_t dir_limit = m->dir_size / 2;
     const uint32_t room = dir_limit > m->dir_used ? dir_limit - m->dir_used : 0;
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
+    // at most one growth task / re-partition per row, and only rows named by a deferred op
+    m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
+    m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
