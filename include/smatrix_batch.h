@@ -80,6 +80,7 @@ typedef struct {
   uint64_t dir_slots;       /* directory capacity */
   uint64_t arena_units;     /* 128-byte units handed out (incl. retired blocks) */
   uint64_t arena_mapped;    /* bytes of HBM mapped for row tables */
+  uint64_t arena_free_units;/* units in retired blocks waiting for reuse */
   uint64_t batches;         /* write batches executed */
   uint64_t rounds;          /* op-kernel rounds over all write batches */
   uint64_t deferred_ops;    /* ops re-run after a structure change */

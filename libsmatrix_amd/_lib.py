@@ -14,7 +14,7 @@ u64p = C.POINTER(C.c_uint64)
 class Stats(C.Structure):
     # include/smatrix_batch.h smatrix_stats_t
     _fields_ = [(n, C.c_uint64) for n in (
-        "rows", "dir_slots", "arena_units", "arena_mapped", "batches", "rounds",
+        "rows", "dir_slots", "arena_units", "arena_mapped", "arena_free_units", "batches", "rounds",
         "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced")] + [
         ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
 

@@ -20,6 +20,7 @@
 // launches between rounds of the op kernel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace smx {
@@ -70,18 +71,33 @@ __host__ __device__ inline void subs_init(SubCtr* sc, uint32_t room) {
 
 enum Op : int { OP_GET = 0, OP_SET = 1, OP_INCR = 2, OP_DECR = 3 };
 
-// device-side control block, one per matrix
+// device-side control block, one per matrix.  The first part is zeroed at the start of every round;
+// the persistent part is owned by the device between readbacks.
+constexpr uint32_t N_CLASSES = 28;     // row block size classes: 16 * 2^c cells, c = log2(size) - 4
 struct Ctl {
+  // ---- per round ----
   uint32_t n_defer;      // ops deferred by the current op round
   uint32_t n_tasks;      // rows flagged for growth by prep
-  uint32_t dir_used;     // rows in the directory
   uint32_t dir_full;     // prep refused a row creation (directory at its limit)
-  uint64_t arena_next;   // bump pointer, units
-  uint64_t grow_units;   // units the flagged growths will need
+  uint32_t arena_oom;    // an allocation did not fit (host maps more and reruns)
+  uint64_t grow_units;   // units the flagged growths will need (upper bound: recycled blocks need none)
   uint32_t n_chunks;     // 64-slot chunks over all growth tasks (old tables)
   uint32_t n_chunks_new; // same over the new tables
-  uint32_t arena_oom;    // an allocation did not fit (host maps more and reruns)
   uint32_t n_rebal;      // big rows whose sub-counter quotas want re-partitioning
+  uint32_t pad0;
+  // ---- persistent ----
+  uint32_t dir_used;     // rows in the directory
+  uint32_t pad1;
+  uint64_t arena_next;   // bump pointer, units
+  int32_t  free_cnt[N_CLASSES];   // retired row blocks ready for reuse, per size class (stack heights)
+};
+constexpr size_t CTL_ROUND_BYTES = 40;
+static_assert(offsetof(Ctl, dir_used) == CTL_ROUND_BYTES, "the per-round part of Ctl is what ctl_reset_round zeroes");
+
+// retired blocks, one stack of block addresses per size class (device arrays grown by the host)
+struct FreeLists {
+  uint32_t* list[N_CLASSES];
+  uint32_t cap[N_CLASSES];
 };
 
 struct GrowTask {
@@ -497,7 +513,7 @@ constexpr uint32_t PREP_THREADS = 1024;
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
-    const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* rebal) {
+    const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* rebal, FreeLists fl) {
   // block-scope scratch of the row-creation step
   __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
   __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
@@ -582,15 +598,29 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
         }
       }
       __syncthreads();
-      // B4. give back what was reserved but not used; one arena reservation for the winners
+      // B4. give back what was reserved but not used; the winners' 16-cell blocks come from the
+      //     stack of retired (zeroed) class-0 blocks first, the rest from ONE arena reservation
       if (threadIdx.x == 0) {
         const uint32_t n_res = l_cnt[3] ? l_cnt[0] : 0u, n_won = l_cnt[1];
         if (n_res > n_won) atomicSub(&ctl->dir_used, n_res - n_won);
-        if (n_won) l_u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)n_won);
+        uint32_t got = 0;
+        int32_t top = 0;
+        if (n_won) {
+          top = atomicSub(&ctl->free_cnt[0], (int32_t)n_won);            // old height
+          got = top > 0 ? min((uint32_t)top, n_won) : 0u;
+          if (got < n_won) atomicAdd(&ctl->free_cnt[0], (int32_t)(n_won - got));
+          if (got < n_won)
+            l_u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)(n_won - got));
+        }
+        l_cnt[2] = got;
+        l_cnt[3] = (uint32_t)top;
       }
       __syncthreads();
       if (won) {
-        const uint64_t u = l_u0 + rank2;
+        const uint32_t got = l_cnt[2];
+        uint64_t u;
+        if (rank2 < got) u = fl.list[0][l_cnt[3] - 1u - rank2];
+        else u = l_u0 + (rank2 - got);
         if (u >= arena_cap_units) ctl->arena_oom = 1;                        // host guarantees this never fires
         else __hip_atomic_store(&dir[hh].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -655,22 +685,52 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
 // home not taken by an earlier cell).  While moving, a new cell holds
 // {key, old_slot+1}; k_grow_finish swaps the index for the value.
 
-// one lane per task: allocate the new block, assign chunk ranges
-__global__ void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units) {
-  uint32_t n = ctl->n_tasks;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    GrowTask& k = tasks[t];
-    uint64_t units = block_units(k.old_lg + 1);
-    uint64_t u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next),
-                           (unsigned long long)units);
-    if (u + units > arena_cap_units) ctl->arena_oom = 1;   // host guarantees this never fires
-    k.new_base = (uint32_t)u;
-    k.count = 0;
-    k.dup = 0;
-    uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
-    uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
-    k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
-    k.chunk0_new = atomicAdd(&ctl->n_chunks_new, nc);
+// allocate the new block of every task -- from the stack of retired blocks of its size class where
+// one is left (popped with one atomic per class and workgroup), else from the arena -- and assign
+// the chunk ranges of the move/finish passes
+__global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl) {
+  __shared__ uint32_t l_want[N_CLASSES], l_got[N_CLASSES];
+  __shared__ int32_t l_top[N_CLASSES];
+  const uint32_t n = ctl->n_tasks;
+  for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += gridDim.x * blockDim.x) {    // block-uniform
+    if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t t = t0 + threadIdx.x;
+    const bool live = t < n;
+    uint32_t cls = 0, rank = 0;
+    if (live) {
+      cls = tasks[t].old_lg + 1 - ROW_FIRST_LG;
+      rank = atomicAdd(&l_want[cls], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < N_CLASSES && l_want[threadIdx.x]) {
+      const uint32_t c = threadIdx.x, w = l_want[c];
+      const int32_t top = atomicSub(&ctl->free_cnt[c], (int32_t)w);
+      const uint32_t got = top > 0 ? min((uint32_t)top, w) : 0u;
+      if (got < w) atomicAdd(&ctl->free_cnt[c], (int32_t)(w - got));
+      l_top[c] = top;
+      l_got[c] = got;
+    }
+    __syncthreads();
+    if (live) {
+      GrowTask& k = tasks[t];
+      uint64_t u;
+      if (rank < l_got[cls]) {
+        u = fl.list[cls][l_top[cls] - 1 - (int32_t)rank];
+      } else {
+        const uint64_t units = block_units(k.old_lg + 1);
+        u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)units);
+        if (u + units > arena_cap_units) ctl->arena_oom = 1;   // host guarantees this never fires
+      }
+      k.new_base = (uint32_t)u;
+      k.count = 0;
+      k.dup = 0;
+      uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
+      uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
+      k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
+      k.chunk0_new = atomicAdd(&ctl->n_chunks_new, nc);
+    }
+    __syncthreads();
   }
 }
 
@@ -799,26 +859,73 @@ __global__ void k_grow_fixdup(const Ctl* ctl, GrowTask* tasks, uint8_t* arena) {
   }
 }
 
-// one lane per task: publish the new table (src/smatrix.c:408-410)
-__global__ void k_grow_commit(const Ctl* ctl, const GrowTask* tasks, DirSlot* dir, uint8_t* arena) {
-  uint32_t n = ctl->n_tasks;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    const GrowTask k = tasks[t];
-    DirSlot& d = dir[k.dslot];
-    const uint32_t lg = k.old_lg + 1;
-    uint32_t count = k.count;
-    if (lg >= BIG_LG && !k.dup) {                     // k_grow_move's sharded count (fixdup recounts itself)
-      const SubCtr* sc = row_subs(arena, k.new_base, lg);
-      for (uint32_t i = 0; i < SUBS; i++) count += sc[i].cnt;
-    }
-    d.meta = META_USED | (lg << META_LG_SHIFT);
-    d.base = k.new_base;
-    d.used = count;
-    if (lg >= BIG_LG) {
-      const uint32_t cap = (1u << lg) / 2u + 1u;
-      subs_init(row_subs(arena, k.new_base, lg), cap > count ? cap - count : 0u);
-    }
+// one wave per 64 old slots: a retired block goes back to its size class's stack ZEROED
+// (row creation and growth rely on fresh blocks being all-empty)
+__global__ __launch_bounds__(256) void k_grow_zero(const Ctl* ctl, const GrowTask* tasks,
+                                                   const uint32_t* map_old, uint8_t* arena) {
+  uint32_t nchunks = ctl->n_chunks;
+  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
+    const GrowTask k = tasks[map_old[ch]];
+    const uint32_t p = (ch - k.chunk0) * 64 + lane;
+    if (p < (1u << k.old_lg)) row_cells(arena, k.old_base)[p] = 0;
   }
+}
+
+// publish the new tables (src/smatrix.c:408-410) and push the old blocks on their classes' stacks
+// (one atomic per class and workgroup; a stack that is full simply lets the block go)
+__global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, const GrowTask* tasks, DirSlot* dir, uint8_t* arena,
+                                                     FreeLists fl) {
+  __shared__ uint32_t l_want[N_CLASSES], l_at[N_CLASSES];
+  const uint32_t n = ctl->n_tasks;
+  for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += gridDim.x * blockDim.x) {    // block-uniform
+    if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t t = t0 + threadIdx.x;
+    const bool live = t < n;
+    GrowTask k = {};
+    uint32_t cls = 0, rank = 0;
+    if (live) {
+      k = tasks[t];
+      DirSlot& d = dir[k.dslot];
+      const uint32_t lg = k.old_lg + 1;
+      uint32_t count = k.count;
+      if (lg >= BIG_LG && !k.dup) {                     // k_grow_move's sharded count (fixdup recounts itself)
+        const SubCtr* sc = row_subs(arena, k.new_base, lg);
+        for (uint32_t i = 0; i < SUBS; i++) count += sc[i].cnt;
+      }
+      d.meta = META_USED | (lg << META_LG_SHIFT);
+      d.base = k.new_base;
+      d.used = count;
+      if (lg >= BIG_LG) {
+        const uint32_t cap = (1u << lg) / 2u + 1u;
+        subs_init(row_subs(arena, k.new_base, lg), cap > count ? cap - count : 0u);
+      }
+      if (k.old_lg >= BIG_LG) {                         // the old block's sub-counter lines, zeroed too
+        uint64_t* z = reinterpret_cast<uint64_t*>(row_subs(arena, k.old_base, k.old_lg));
+        for (uint32_t i = 0; i < SUBS * 8; i++) z[i] = 0;
+      }
+      cls = k.old_lg - ROW_FIRST_LG;
+      rank = atomicAdd(&l_want[cls], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < N_CLASSES && l_want[threadIdx.x])
+      l_at[threadIdx.x] = (uint32_t)atomicAdd(&ctl->free_cnt[threadIdx.x], (int32_t)l_want[threadIdx.x]);
+    __syncthreads();
+    if (live) {
+      const uint32_t at = l_at[cls] + rank;
+      if (at < fl.cap[cls]) fl.list[cls][at] = k.old_base;
+    }
+    __syncthreads();
+  }
+}
+
+// stacks may have been over-filled by k_grow_commit (entries beyond a stack's capacity were dropped)
+__global__ void k_free_clamp(Ctl* ctl, FreeLists fl) {
+  const uint32_t c = threadIdx.x;
+  if (c < N_CLASSES && ctl->free_cnt[c] > (int32_t)fl.cap[c]) ctl->free_cnt[c] = (int32_t)fl.cap[c];
 }
 
 // big rows flagged by prep: fold the sub-counters into `used`, share out what room is left

@@ -200,6 +200,8 @@ struct Matrix {
   DevBuf<uint32_t> defer[2];
   DevBuf<GrowTask> tasks;
   DevBuf<uint32_t> rebal;
+  FreeLists fl = {};                    // their pointers/capacities as passed to the kernels
+  int32_t free_cnt[N_CLASSES] = {0};    // host mirror of the stack heights (last readback)
   DevBuf<uint32_t> map_old, map_new;
   DevBuf<uint64_t> cellp;
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
@@ -220,12 +222,18 @@ struct Matrix {
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
 
 void ctl_reset_round(Matrix* m, hipStream_t s) {
-  // zero everything except dir_used / arena_next (kept by value)
+  HIP_OK(hipMemsetAsync(m->d_ctl, 0, CTL_ROUND_BYTES, s));     // the persistent part stays on the device
+}
+
+// host -> device for the persistent part (open, file load)
+void ctl_push_persistent(Matrix* m, hipStream_t s) {
   Ctl c = {};
   c.dir_used = m->dir_used;
   c.arena_next = m->arena_next;
+  memcpy(c.free_cnt, m->free_cnt, sizeof c.free_cnt);
   *m->h_ctl = c;
   HIP_OK(hipMemcpyAsync(m->d_ctl, m->h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
 }
 
 void ctl_read(Matrix* m, hipStream_t s) {
@@ -233,6 +241,22 @@ void ctl_read(Matrix* m, hipStream_t s) {
   HIP_OK(hipStreamSynchronize(s));
   m->dir_used = m->h_ctl->dir_used;
   m->arena_next = m->h_ctl->arena_next;
+  memcpy(m->free_cnt, m->h_ctl->free_cnt, sizeof m->free_cnt);
+}
+
+// room for `extra` more entries on the stack of class c (contents preserved)
+void ensure_free_cap(Matrix* m, uint32_t c, uint64_t extra, hipStream_t s) {
+  const uint64_t have = m->free_cnt[c] > 0 ? (uint64_t)m->free_cnt[c] : 0;
+  const uint64_t need = have + extra;
+  if (need <= m->fl.cap[c]) return;
+  const uint64_t ncap = std::max<uint64_t>(need, (uint64_t)m->fl.cap[c] * 2);
+  uint32_t* np = nullptr;
+  HIP_OK(hipMalloc(&np, ncap * sizeof(uint32_t)));
+  if (have) HIP_OK(hipMemcpyAsync(np, m->fl.list[c], have * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+  if (m->fl.list[c]) HIP_OK(hipFree(m->fl.list[c]));
+  m->fl.list[c] = np;
+  m->fl.cap[c] = (uint32_t)std::min<uint64_t>(ncap, 0x7fffffffu);
 }
 
 void ensure_arena_free(Matrix* m, uint64_t units, hipStream_t s) {
@@ -327,8 +351,9 @@ void grow_rows(Matrix* m, hipStream_t s) {
   m->map_new.need((size_t)nt + gu / 4 + 1);
   m->map_old.need((size_t)nt + gu / 8 + 1);
   const uint64_t cap_units = m->arena.mapped / UNIT_BYTES;
+  for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, nt, s);     // every task retires one block
   hipLaunchKernelGGL(k_grow_plan, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
-                     m->d_ctl, m->tasks.p, cap_units);
+                     m->d_ctl, m->tasks.p, cap_units, m->fl);
   hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)nt * 64), 2048)),
                      dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->map_new.p);
   const uint64_t oc_bound = (uint64_t)nt + gu / 8, nc_bound = (uint64_t)nt + gu / 4;
@@ -338,8 +363,11 @@ void grow_rows(Matrix* m, hipStream_t s) {
                      dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_fixdup, dim3(std::min<uint32_t>(blocks_for(nt, 64), 1024)), dim3(64), 0, s,
                      m->d_ctl, m->tasks.p, m->arena.base);
+  hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
+                     dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
-                     m->d_ctl, m->tasks.p, m->d_dir, m->arena.base);
+                     m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
+  hipLaunchKernelGGL(k_free_clamp, dim3(1), dim3(64), 0, s, m->d_ctl, m->fl);
   HIP_OK(hipGetLastError());
   if (m->trace_rounds && nt > 1000) {      // who grows?  (cells moved, by log2 of the old row size)
     std::vector<GrowTask> ht(nt);
@@ -352,7 +380,7 @@ void grow_rows(Matrix* m, hipStream_t s) {
       if (cnt[lg]) fprintf(stderr, " 2^%d x%llu (%.1fM cells)", lg, (unsigned long long)cnt[lg], cnt[lg] * (double)(1ull << lg) / 1e6);
     fprintf(stderr, "\n");
   }
-  m->arena_next += gu;   // exact: plan hands out precisely grow_units
+  m->arena_next += gu;   // upper bound until the next readback (recycled blocks take nothing from the arena)
   m->st.rows_grown += nt;
 }
 
@@ -381,7 +409,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), 2048)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
-                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->rebal.p);
+                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->rebal.p, m->fl);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
@@ -495,6 +523,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipMemsetAsync(m->d_dir, 0, (size_t)m->dir_size * sizeof(DirSlot), m->stream));
   m->arena.init(dev, 4u << 20, m->stream);
   HIP_OK(hipStreamSynchronize(m->stream));
+  ctl_push_persistent(m, m->stream);
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
   const char* prof = getenv("SMATRIX_PROFILE");
@@ -528,6 +557,8 @@ void smatrix_close(smatrix_t* self) {
       if (m->d_small) (void)hipFree(m->d_small);
       if (m->h_small) (void)hipHostFree(m->h_small);
       for (auto& d : m->defer) d.release();
+      for (uint32_t c = 0; c < N_CLASSES; c++)
+        if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
       m->tasks.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -835,6 +866,9 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   m->st.rows = m->dir_used;
   m->st.dir_slots = m->dir_size;
   m->st.arena_units = m->arena_next;
+  m->st.arena_free_units = 0;
+  for (uint32_t c = 0; c < N_CLASSES; c++)
+    if (m->free_cnt[c] > 0) m->st.arena_free_units += (uint64_t)m->free_cnt[c] * block_units(c + ROW_FIRST_LG);
   m->st.arena_mapped = m->arena.mapped;
   *out = m->st;
 }
