@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void k_grow_zero(const Ctl* ctl, const GrowTas
 }
 
 // publish the new tables (src/smatrix.c:408-410) and push the old blocks on their classes' stacks
-// (one atomic per class and workgroup; a stack that is full simply lets the block go)
+// (one atomic per class and workgroup; the host sized every stack for this round's pushes beforehand)
 __global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, const GrowTask* tasks, DirSlot* dir, uint8_t* arena,
                                                      FreeLists fl) {
   __shared__ uint32_t l_want[N_CLASSES], l_at[N_CLASSES];
@@ -915,17 +915,10 @@ __global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, const GrowTask* t
       l_at[threadIdx.x] = (uint32_t)atomicAdd(&ctl->free_cnt[threadIdx.x], (int32_t)l_want[threadIdx.x]);
     __syncthreads();
     if (live) {
-      const uint32_t at = l_at[cls] + rank;
-      if (at < fl.cap[cls]) fl.list[cls][at] = k.old_base;
+      fl.list[cls][l_at[cls] + rank] = k.old_base;
     }
     __syncthreads();
   }
-}
-
-// stacks may have been over-filled by k_grow_commit (entries beyond a stack's capacity were dropped)
-__global__ void k_free_clamp(Ctl* ctl, FreeLists fl) {
-  const uint32_t c = threadIdx.x;
-  if (c < N_CLASSES && ctl->free_cnt[c] > (int32_t)fl.cap[c]) ctl->free_cnt[c] = (int32_t)fl.cap[c];
 }
 
 // big rows flagged by prep: fold the sub-counters into `used`, share out what room is left

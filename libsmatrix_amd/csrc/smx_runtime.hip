@@ -367,7 +367,6 @@ void grow_rows(Matrix* m, hipStream_t s) {
                      dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
-  hipLaunchKernelGGL(k_free_clamp, dim3(1), dim3(64), 0, s, m->d_ctl, m->fl);
   HIP_OK(hipGetLastError());
   if (m->trace_rounds && nt > 1000) {      // who grows?  (cells moved, by log2 of the old row size)
     std::vector<GrowTask> ht(nt);
@@ -466,7 +465,11 @@ Matrix* M(smatrix_t* self) { return static_cast<Matrix*>(self->impl); }
 
 void refresh_public(smatrix_t* self) {
   Matrix* m = M(self);
-  self->mem = (uint64_t)m->dir_size * sizeof(DirSlot) + m->arena_next * UNIT_BYTES;
+  uint64_t free_units = 0;
+  for (uint32_t c = 0; c < N_CLASSES; c++)
+    if (m->free_cnt[c] > 0) free_units += (uint64_t)m->free_cnt[c] * block_units(c + ROW_FIRST_LG);
+  const uint64_t live_units = m->arena_next > free_units ? m->arena_next - free_units : 0;
+  self->mem = (uint64_t)m->dir_size * sizeof(DirSlot) + live_units * UNIT_BYTES;
 }
 
 void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, const uint32_t* y,
