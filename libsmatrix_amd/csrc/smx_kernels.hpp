@@ -84,14 +84,15 @@ struct Ctl {
   uint32_t n_chunks;     // 64-slot chunks over all growth tasks (old tables)
   uint32_t n_chunks_new; // same over the new tables
   uint32_t n_rebal;      // big rows whose sub-counter quotas want re-partitioning
-  uint32_t pad0;
+  uint32_t n_kind[4];    // growth tasks by kind (grow_kind): LDS by wave / workgroup / large workgroup, chunked
+  uint32_t pad0[3];
   // ---- persistent ----
   uint32_t dir_used;     // rows in the directory
   uint32_t pad1;
   uint64_t arena_next;   // bump pointer, units
   int32_t  free_cnt[N_CLASSES];   // retired row blocks ready for reuse, per size class (stack heights)
 };
-constexpr size_t CTL_ROUND_BYTES = 40;
+constexpr size_t CTL_ROUND_BYTES = 64;    // one aligned fill
 static_assert(offsetof(Ctl, dir_used) == CTL_ROUND_BYTES, "the per-round part of Ctl is what ctl_reset_round zeroes");
 
 // retired blocks, one stack of block addresses per size class (device arrays grown by the host)
@@ -110,6 +111,17 @@ struct GrowTask {
   uint32_t chunk0_new;   // same for the new table
   uint32_t dup;          // the old table holds one key twice (see k_grow_fixdup)
 };
+
+// How a row is doubled: tables whose old cells and new slots fit in LDS are rebuilt there by one wave
+// (kind 0), one 256-lane workgroup (kind 1) or one 1024-lane workgroup (kind 2); larger ones go through
+// the chunked global-memory passes (kind 3).  LDS per task: 16 bytes per old cell.
+constexpr uint32_t GROW_LG0 = 8;      // old size <= 256 cells : 4 KB per wave
+constexpr uint32_t GROW_LG1 = 11;     // old size <= 2048 cells: 32 KB per workgroup
+constexpr uint32_t GROW_LG2 = 13;     // old size <= 8192 cells: 128 KB, one workgroup per CU
+constexpr uint32_t GROW_CHUNKED = 3;
+__host__ __device__ inline uint32_t grow_kind(uint32_t old_lg) {
+  return old_lg <= GROW_LG0 ? 0u : old_lg <= GROW_LG1 ? 1u : old_lg <= GROW_LG2 ? 2u : GROW_CHUNKED;
+}
 
 __device__ inline uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85ebca6bU; h ^= h >> 13; h *= 0xc2b2ae35U; h ^= h >> 16;
@@ -513,7 +525,8 @@ constexpr uint32_t PREP_THREADS = 1024;
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
-    const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* rebal, FreeLists fl) {
+    const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
+    FreeLists fl) {
   // block-scope scratch of the row-creation step
   __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
   __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
@@ -648,6 +661,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     }
     // D. once per row with an absent key: grow it iff it stands at the reference's threshold
     //    (src/smatrix.c:346-348); a big row with room left only has its quotas re-partitioned
+    bool mk = false;                                 // this lane files a growth task
+    uint32_t t_lg = 0, t_base = 0;
     per_distinct(absent, h, [&](uint32_t h0) {
       const uint32_t meta = __hip_atomic_load(&dir[h0].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (meta & (META_GROW | META_REBAL)) return;
@@ -657,20 +672,39 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
       if (lg0 >= BIG_LG) used += subs_sum(row_subs(arena, base0, lg0));
       if (used > (1u << lg0) / 2u) {
         uint32_t old = atomicOr(&dir[h0].meta, META_GROW);
-        if (!(old & META_GROW)) {
-          uint32_t k = atomicAdd(&ctl->n_tasks, 1u);
-          tasks[k].dslot = h0;
-          tasks[k].old_lg = lg0;
-          tasks[k].old_base = base0;
-          atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units),
-                    (unsigned long long)block_units(lg0 + 1));
-        }
+        if (!(old & META_GROW)) { mk = true; t_lg = lg0; t_base = base0; }
       } else if (lg0 >= BIG_LG) {
         // room is left, but this op's sub-counter had used up its share: re-partition
         uint32_t old = atomicOr(&dir[h0].meta, META_REBAL);
         if (!(old & META_REBAL)) rebal[atomicAdd(&ctl->n_rebal, 1u)] = h0;
       }
     });
+    // the task list and the per-kind work lists: ONE reservation per wave and list (a returning
+    // atomic per task on these few words cost 0.7 ms per batch)
+    const uint64_t mm = __ballot(mk);
+    if (mm) {
+      const uint32_t lane = __lane_id();
+      const uint64_t below = (1ull << lane) - 1ull;
+      uint32_t b = 0;
+      if (lane == (uint32_t)__ffsll((unsigned long long)mm) - 1u) b = atomicAdd(&ctl->n_tasks, (uint32_t)__popcll(mm));
+      b = __shfl(b, __ffsll((unsigned long long)mm) - 1);
+      const uint32_t k = b + (uint32_t)__popcll(mm & below);
+      const uint32_t kind = grow_kind(t_lg);
+      for (uint32_t kk = 0; kk <= GROW_CHUNKED; kk++) {
+        const uint64_t mk2 = __ballot(mk && kind == kk);
+        if (!mk2) continue;
+        uint32_t r = 0;
+        if (lane == (uint32_t)__ffsll((unsigned long long)mk2) - 1u) r = atomicAdd(&ctl->n_kind[kk], (uint32_t)__popcll(mk2));
+        r = __shfl(r, __ffsll((unsigned long long)mk2) - 1);
+        if (mk && kind == kk && kk != GROW_CHUNKED) klist[kk * kcap + r + (uint32_t)__popcll(mk2 & below)] = k;
+      }
+      if (mk) {
+        tasks[k].dslot = h;
+        tasks[k].old_lg = t_lg;
+        tasks[k].old_base = t_base;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units), (unsigned long long)block_units(t_lg + 1));
+      }
+    }
   }
 }
 
@@ -725,10 +759,12 @@ __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, ui
       k.new_base = (uint32_t)u;
       k.count = 0;
       k.dup = 0;
-      uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
-      uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
-      k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
-      k.chunk0_new = atomicAdd(&ctl->n_chunks_new, nc);
+      if (grow_kind(k.old_lg) == GROW_CHUNKED) {
+        uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
+        uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
+        k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
+        k.chunk0_new = atomicAdd(&ctl->n_chunks_new, nc);
+      }
     }
     __syncthreads();
   }
@@ -743,10 +779,79 @@ __global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask
   uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t t = wave; t < n; t += nwaves) {
     const GrowTask k = tasks[t];
+    if (grow_kind(k.old_lg) != GROW_CHUNKED) continue;
     uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
     uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
     for (uint32_t c = lane; c < oc; c += 64) map_old[k.chunk0 + c] = t;
     for (uint32_t c = lane; c < nc; c += 64) map_new[k.chunk0_new + c] = t;
+  }
+}
+
+// Rows whose old and new table fit in LDS: one workgroup (THREADS = 64: one wave) per task.
+// The same priority probing as k_grow_move, but on a table of OLD SLOT INDICES in LDS, where an
+// arrival is a single 32-bit atomicMin: the smaller index (earlier old slot) keeps the slot, the
+// larger one moves on.  Then the duplicate check of k_grow_finish, the new table written out
+// coalesced, and the old block zeroed for reuse -- one read and one write of each block in all.
+template <int THREADS, uint32_t MAX_LG>
+__global__ __launch_bounds__(THREADS) void k_grow_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
+                                                      uint32_t kind, uint8_t* arena) {
+  extern __shared__ uint64_t l_old[];                               // 2^MAX_LG cells ...
+  uint32_t* l_tab = reinterpret_cast<uint32_t*>(l_old + (1u << MAX_LG));   // ... and 2^(MAX_LG+1) slot indices
+  __shared__ uint32_t l_cnt, l_dup;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  const uint32_t n = ctl->n_kind[kind];
+  for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {                   // block-uniform
+    const uint32_t t = list[li];
+    const uint32_t old_lg = tasks[t].old_lg;
+    const uint32_t old_size = 1u << old_lg, new_size = 2u << old_lg, nmask = new_size - 1u;
+    uint64_t* O = row_cells(arena, tasks[t].old_base);
+    uint64_t* T = row_cells(arena, tasks[t].new_base);
+    if (threadIdx.x == 0) { l_cnt = 0; l_dup = 0; }
+    for (uint32_t q = threadIdx.x; q < new_size; q += THREADS) l_tab[q] = NONE;
+    for (uint32_t p = threadIdx.x; p < old_size; p += THREADS) l_old[p] = O[p];
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t p = threadIdx.x; p < old_size; p += THREADS) {
+      const uint64_t c = l_old[p];
+      if (c == 0) continue;
+      mine++;
+      uint32_t cur = p, i = cell_key(c) & nmask;
+      for (;;) {
+        const uint32_t prev = atomicMin(&l_tab[i], cur);
+        if (prev == NONE) break;                     // the slot was free
+        if (prev > cur) cur = prev;                  // evicted a later cell: carry it onward
+        i = (i + 1) & nmask;
+      }
+    }
+    if (mine) atomicAdd(&l_cnt, mine);
+    __syncthreads();
+    // a key that a probe from its home finds in ANOTHER slot first is a duplicate (k_grow_fixdup)
+    for (uint32_t q = threadIdx.x; q < new_size; q += THREADS) {
+      const uint32_t r = l_tab[q];
+      if (r == NONE) continue;
+      const uint32_t key = cell_key(l_old[r]);
+      uint32_t i = key & nmask;
+      while (i != q) {
+        const uint32_t r2 = l_tab[i];
+        if (r2 == NONE || cell_key(l_old[r2]) == key) break;
+        i = (i + 1) & nmask;
+      }
+      if (i != q) l_dup = 1;
+    }
+    __syncthreads();
+    const uint32_t dup = l_dup;
+    if (!dup) {
+      for (uint32_t q = threadIdx.x; q < new_size; q += THREADS) {
+        const uint32_t r = l_tab[q];
+        T[q] = r == NONE ? 0ull : l_old[r];
+      }
+      for (uint32_t p = threadIdx.x; p < old_size; p += THREADS) O[p] = 0;
+    }
+    if (threadIdx.x == 0) {
+      tasks[t].count = l_cnt;
+      tasks[t].dup = dup;                            // fixdup redoes the row from the (intact) old block
+    }
+    __syncthreads();
   }
 }
 
@@ -856,6 +961,8 @@ __global__ void k_grow_fixdup(const Ctl* ctl, GrowTask* tasks, uint8_t* arena) {
       T[i] = c;
     }
     k.count = used;
+    if (grow_kind(k.old_lg) != GROW_CHUNKED)         // k_grow_lds left the old block for this redo
+      for (uint32_t p = 0; p < old_size; p++) row_cells(arena, k.old_base)[p] = 0;
   }
 }
 

@@ -199,6 +199,8 @@ struct Matrix {
 
   DevBuf<uint32_t> defer[2];
   DevBuf<GrowTask> tasks;
+  DevBuf<uint32_t> klist;               // growth tasks of kind k at [k * klist_cap, ...), k = 0..2
+  uint32_t klist_cap = 0;
   DevBuf<uint32_t> rebal;
   FreeLists fl = {};                    // their pointers/capacities as passed to the kernels
   int32_t free_cnt[N_CLASSES] = {0};    // host mirror of the stack heights (last readback)
@@ -357,17 +359,31 @@ void grow_rows(Matrix* m, hipStream_t s) {
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, nt, s);     // every task retires one block
   hipLaunchKernelGGL(k_grow_plan, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, cap_units, m->fl);
-  hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)nt * 64), 2048)),
-                     dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->map_new.p);
-  const uint64_t oc_bound = (uint64_t)nt + gu / 8, nc_bound = (uint64_t)nt + gu / 4;
-  hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                     dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
-  hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
-                     dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
+  const uint32_t* nk = m->h_ctl->n_kind;
+  const uint32_t n_chunked = nk[GROW_CHUNKED];
+  if (nk[0])
+    hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), 16u << GROW_LG0, s,
+                       m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base);
+  if (nk[1])
+    hipLaunchKernelGGL((k_grow_lds<256, GROW_LG1>), dim3(std::min<uint32_t>(nk[1], 4096)), dim3(256), 16u << GROW_LG1, s,
+                       m->d_ctl, m->tasks.p, m->klist.p + m->klist_cap, 1u, m->arena.base);
+  if (nk[2])
+    hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), 16u << GROW_LG2, s,
+                       m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base);
+  const uint64_t oc_bound = (uint64_t)n_chunked + gu / 8, nc_bound = (uint64_t)n_chunked + gu / 4;
+  if (n_chunked) {
+    hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)nt * 64), 2048)),
+                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->map_new.p);
+    hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
+                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+    hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
+                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
+  }
   hipLaunchKernelGGL(k_grow_fixdup, dim3(std::min<uint32_t>(blocks_for(nt, 64), 1024)), dim3(64), 0, s,
                      m->d_ctl, m->tasks.p, m->arena.base);
-  hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                     dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+  if (n_chunked)
+    hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
+                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
   HIP_OK(hipGetLastError());
@@ -405,13 +421,16 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
     // at most one growth task / re-partition per row, and only rows named by a deferred op
     m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
+    m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
+    m->klist.need(3 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), 2048)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
-                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->rebal.p, m->fl);
+                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
+                       m->rebal.p, m->fl);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
@@ -530,6 +549,8 @@ smatrix_t* smatrix_open(const char* fname) {
   m->arena.init(dev, 4u << 20, m->stream);
   HIP_OK(hipStreamSynchronize(m->stream));
   ctl_push_persistent(m, m->stream);
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
@@ -566,7 +587,7 @@ void smatrix_close(smatrix_t* self) {
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
-      m->tasks.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
+      m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -736,6 +757,8 @@ int smatrix_cf_neighbors_batch(smatrix_t* self, size_t n, const uint32_t* items,
   HIP_OK(hipMalloc(&d_counts, n * 4));
   HIP_OK(hipMalloc(&d_ids, std::max<uint64_t>(total, 1) * 4));
   HIP_OK(hipMalloc(&d_scores, std::max<uint64_t>(total, 1) * 8));
+  HIP_OK(hipMemset(d_ids, 0, std::max<uint64_t>(total, 1) * 4));        // slots beyond a row's count read 0
+  HIP_OK(hipMemset(d_scores, 0, std::max<uint64_t>(total, 1) * 8));
   HIP_OK(hipMemcpy(d_items, items, n * 4, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice));
   smatrix_cf_neighbors_batch_dev(self, n, d_items, d_off, d_ids, d_scores, d_counts, nullptr);
