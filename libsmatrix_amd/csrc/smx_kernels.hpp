@@ -531,6 +531,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
   __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
   __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
   __shared__ unsigned long long l_u0;
+  __shared__ uint32_t l_k[8], l_kb[8];             // growth tasks filed by this block: total, by kind; list bases
+  __shared__ unsigned long long l_units;
   const uint32_t n = ctl->n_defer;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += stride) {        // block-uniform trip count
@@ -661,49 +663,68 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     }
     // D. once per row with an absent key: grow it iff it stands at the reference's threshold
     //    (src/smatrix.c:346-348); a big row with room left only has its quotas re-partitioned
-    bool mk = false;                                 // this lane files a growth task
-    uint32_t t_lg = 0, t_base = 0;
-    per_distinct(absent, h, [&](uint32_t h0) {
-      const uint32_t meta = __hip_atomic_load(&dir[h0].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (meta & (META_GROW | META_REBAL)) return;
-      const uint32_t lg0 = meta_lg(meta);
-      const uint32_t base0 = __hip_atomic_load(&dir[h0].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t used = __hip_atomic_load(&dir[h0].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lg0 >= BIG_LG) used += subs_sum(row_subs(arena, base0, lg0));
-      if (used > (1u << lg0) / 2u) {
-        uint32_t old = atomicOr(&dir[h0].meta, META_GROW);
-        if (!(old & META_GROW)) { mk = true; t_lg = lg0; t_base = base0; }
-      } else if (lg0 >= BIG_LG) {
-        // room is left, but this op's sub-counter had used up its share: re-partition
-        uint32_t old = atomicOr(&dir[h0].meta, META_REBAL);
-        if (!(old & META_REBAL)) rebal[atomicAdd(&ctl->n_rebal, 1u)] = h0;
+    //    "Once per row" is decided in two steps: a wave-level election (ballots), then the wave
+    //    leaders meet in a block-level LDS set.  All ~2400 waves of a launch are resident at once and
+    //    most of them hold an op of the same few hot rows; with the wave election alone every one of
+    //    them sent the flag atomic (and, for big rows, 64 sub-counter loads) to the same address.
+    bool lead = false;
+    per_distinct(absent, h, [&](uint32_t) { lead = true; });
+    if (__syncthreads_or(lead)) {
+      for (uint32_t i = threadIdx.x; i < 2 * PREP_THREADS; i += PREP_THREADS) l_set[i] = 0xFFFFFFFFu;
+      if (threadIdx.x < 8) l_k[threadIdx.x] = 0;
+      if (threadIdx.x == 0) l_units = 0;
+      __syncthreads();
+      if (lead) {
+        uint32_t q = (h * 0x9E3779B1u) >> 21;              // 11 bits
+        for (;;) {
+          const uint32_t prev = atomicCAS(&l_set[q], 0xFFFFFFFFu, h);
+          if (prev == 0xFFFFFFFFu) break;                 // first of its row in this block
+          if (prev == h) { lead = false; break; }
+          q = (q + 1) & (2 * PREP_THREADS - 1);
+        }
       }
-    });
-    // the task list and the per-kind work lists: ONE reservation per wave and list (a returning
-    // atomic per task on these few words cost 0.7 ms per batch)
-    const uint64_t mm = __ballot(mk);
-    if (mm) {
-      const uint32_t lane = __lane_id();
-      const uint64_t below = (1ull << lane) - 1ull;
-      uint32_t b = 0;
-      if (lane == (uint32_t)__ffsll((unsigned long long)mm) - 1u) b = atomicAdd(&ctl->n_tasks, (uint32_t)__popcll(mm));
-      b = __shfl(b, __ffsll((unsigned long long)mm) - 1);
-      const uint32_t k = b + (uint32_t)__popcll(mm & below);
-      const uint32_t kind = grow_kind(t_lg);
-      for (uint32_t kk = 0; kk <= GROW_CHUNKED; kk++) {
-        const uint64_t mk2 = __ballot(mk && kind == kk);
-        if (!mk2) continue;
-        uint32_t r = 0;
-        if (lane == (uint32_t)__ffsll((unsigned long long)mk2) - 1u) r = atomicAdd(&ctl->n_kind[kk], (uint32_t)__popcll(mk2));
-        r = __shfl(r, __ffsll((unsigned long long)mk2) - 1);
-        if (mk && kind == kk && kk != GROW_CHUNKED) klist[kk * kcap + r + (uint32_t)__popcll(mk2 & below)] = k;
+      bool mk = false;                               // this lane files a growth task
+      uint32_t t_lg = 0, t_base = 0, kind = 0, rk = 0, rkk = 0;
+      if (lead) {
+        const uint32_t meta = __hip_atomic_load(&dir[h].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(meta & (META_GROW | META_REBAL))) {
+          t_lg = meta_lg(meta);
+          t_base = __hip_atomic_load(&dir[h].base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t used = __hip_atomic_load(&dir[h].used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (t_lg >= BIG_LG) used += subs_sum(row_subs(arena, t_base, t_lg));
+          if (used > (1u << t_lg) / 2u) {
+            const uint32_t old = atomicOr(&dir[h].meta, META_GROW);
+            mk = !(old & META_GROW);
+          } else if (t_lg >= BIG_LG) {
+            // room is left, but this op's sub-counter had used up its share: re-partition
+            const uint32_t old = atomicOr(&dir[h].meta, META_REBAL);
+            if (!(old & META_REBAL)) rebal[atomicAdd(&ctl->n_rebal, 1u)] = h;
+          }
+        }
       }
+      // the task list and the per-kind work lists are reserved ONCE PER BLOCK, all five counters in
+      // one wave instruction: every atomic instruction on these few words of one line queues at the
+      // memory side (per task: 0.7 ms per batch; per wave: still 0.13 ms)
       if (mk) {
+        kind = grow_kind(t_lg);
+        rk = atomicAdd(&l_k[0], 1u);
+        rkk = atomicAdd(&l_k[1 + kind], 1u);
+        atomicAdd(&l_units, (unsigned long long)block_units(t_lg + 1));
+      }
+      __syncthreads();
+      if (threadIdx.x < 5 && l_k[threadIdx.x])
+        l_kb[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? &ctl->n_tasks : &ctl->n_kind[threadIdx.x - 1], l_k[threadIdx.x]);
+      if (threadIdx.x == 0 && l_units)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units), l_units);
+      __syncthreads();
+      if (mk) {
+        const uint32_t k = l_kb[0] + rk;
+        if (kind != GROW_CHUNKED) klist[kind * kcap + l_kb[1 + kind] + rkk] = k;
         tasks[k].dslot = h;
         tasks[k].old_lg = t_lg;
         tasks[k].old_base = t_base;
-        atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->grow_units), (unsigned long long)block_units(t_lg + 1));
       }
+      __syncthreads();                                     // the LDS scratch is reused by the next trip
     }
   }
 }
