@@ -123,6 +123,14 @@ __host__ __device__ inline uint32_t grow_kind(uint32_t old_lg) {
   return old_lg <= GROW_LG0 ? 0u : old_lg <= GROW_LG1 ? 1u : old_lg <= GROW_LG2 ? 2u : GROW_CHUNKED;
 }
 
+// A kernel body runs either as its own launch (one workgroup per blockIdx) or as one phase of the
+// persistent round kernel (k_rounds), which gives every resident workgroup a share of a VIRTUAL grid.
+struct VGrid { uint32_t bid, nb; };
+#define SMX_VG (VGrid{blockIdx.x, gridDim.x})
+// counters other workgroups have just written (phases of one launch are separated by grid syncs)
+__device__ inline uint32_t aload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t aload(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ inline uint32_t fmix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85ebca6bU; h ^= h >> 13; h *= 0xc2b2ae35U; h ^= h >> 16;
   return h;
@@ -301,20 +309,30 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
 }
 
 template <int OP>
+__device__ __forceinline__ void apply_body(
+    VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
+  for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
+    const uint32_t t = t0 + threadIdx.x;
+    const bool live = t < n;
+    uint32_t j = 0;
+    bool deferred = false;
+    if (live) {
+      j = idx ? idx[t] : t;
+      uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
+      if (!deferred) out[j] = r;
+    }
+    if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
+  }
+}
+
+template <int OP>
 __global__ __launch_bounds__(256) void k_apply(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = t < n;
-  uint32_t j = 0;
-  bool deferred = false;
-  if (live) {
-    j = idx ? idx[t] : t;
-    uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
-    if (!deferred) out[j] = r;
-  }
-  if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
+  apply_body<OP>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer);
 }
 
 // ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
@@ -522,8 +540,8 @@ __device__ inline void per_distinct(bool want, uint32_t key, F f) {
 
 constexpr uint32_t PREP_THREADS = 1024;
 
-__global__ __launch_bounds__(PREP_THREADS) void k_prep(
-    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
+__device__ __forceinline__ void prep_body(
+    VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
     FreeLists fl) {
@@ -533,9 +551,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
   __shared__ unsigned long long l_u0;
   __shared__ uint32_t l_k[8], l_kb[8];             // growth tasks filed by this block: total, by kind; list bases
   __shared__ unsigned long long l_units;
-  const uint32_t n = ctl->n_defer;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += stride) {        // block-uniform trip count
+  const uint32_t n = aload(&ctl->n_defer);
+  const uint32_t stride = g.nb * blockDim.x;
+  for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += stride) {             // block-uniform trip count
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
     uint32_t X = 0, Y = 0;
@@ -729,6 +747,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
   }
 }
 
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
+    uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
+    const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
+    FreeLists fl) {
+  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl);
+}
+
 // ---- growth -------------------------------------------------------------------
 //
 // smatrix_rmap_resize (src/smatrix.c:383-416) doubles the table and re-inserts
@@ -743,11 +769,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
 // allocate the new block of every task -- from the stack of retired blocks of its size class where
 // one is left (popped with one atomic per class and workgroup), else from the arena -- and assign
 // the chunk ranges of the move/finish passes
-__global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl) {
+__device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl) {
   __shared__ uint32_t l_want[N_CLASSES], l_got[N_CLASSES];
   __shared__ int32_t l_top[N_CLASSES];
-  const uint32_t n = ctl->n_tasks;
-  for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += gridDim.x * blockDim.x) {    // block-uniform
+  const uint32_t n = aload(&ctl->n_tasks);
+  for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t t = t0 + threadIdx.x;
@@ -791,13 +817,17 @@ __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, ui
   }
 }
 
+__global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl) {
+  grow_plan_body(SMX_VG, ctl, tasks, arena_cap_units, fl);
+}
+
 // chunk -> task maps, filled one wave per task
-__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks,
-                                                  uint32_t* map_old, uint32_t* map_new) {
-  uint32_t n = ctl->n_tasks;
-  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const GrowTask* tasks,
+                                              uint32_t* map_old, uint32_t* map_new) {
+  uint32_t n = aload(&ctl->n_tasks);
+  uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t t = wave; t < n; t += nwaves) {
     const GrowTask k = tasks[t];
     if (grow_kind(k.old_lg) != GROW_CHUNKED) continue;
@@ -807,82 +837,108 @@ __global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask
     for (uint32_t c = lane; c < nc; c += 64) map_new[k.chunk0_new + c] = t;
   }
 }
+__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks,
+                                                  uint32_t* map_old, uint32_t* map_new) {
+  grow_map_body(SMX_VG, ctl, tasks, map_old, map_new);
+}
 
-// Rows whose old and new table fit in LDS: one workgroup (THREADS = 64: one wave) per task.
+// Rows whose old and new table fit in LDS are rebuilt there by one wave or one workgroup (the SCOPE).
 // The same priority probing as k_grow_move, but on a table of OLD SLOT INDICES in LDS, where an
 // arrival is a single 32-bit atomicMin: the smaller index (earlier old slot) keeps the slot, the
 // larger one moves on.  Then the duplicate check of k_grow_finish, the new table written out
 // coalesced, and the old block zeroed for reuse -- one read and one write of each block in all.
+template <uint32_t THREADS>
+struct BlockScope {
+  static constexpr uint32_t T = THREADS;
+  __device__ static uint32_t tid() { return threadIdx.x; }
+  __device__ static void sync() { __syncthreads(); }
+};
+struct WaveScope {                                   // the lanes of one wave; LDS traffic of a wave is in order
+  static constexpr uint32_t T = 64;
+  __device__ static uint32_t tid() { return __lane_id(); }
+  __device__ static void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+//   l_old : 2^old_lg cells, l_tab : 2^(old_lg+1) slot indices, l_cd : {count, dup}, all private to the scope
+template <typename S>
+__device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, uint64_t* l_old, uint32_t* l_tab,
+                                              uint32_t* l_cd) {
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  const uint32_t tid = S::tid();
+  const uint32_t old_lg = task->old_lg;
+  const uint32_t old_size = 1u << old_lg, new_size = 2u << old_lg, nmask = new_size - 1u;
+  uint64_t* O = row_cells(arena, task->old_base);
+  uint64_t* T = row_cells(arena, task->new_base);
+  if (tid == 0) { l_cd[0] = 0; l_cd[1] = 0; }
+  for (uint32_t q = tid; q < new_size; q += S::T) l_tab[q] = NONE;
+  for (uint32_t p = tid; p < old_size; p += S::T) l_old[p] = O[p];
+  S::sync();
+  uint32_t mine = 0;
+  for (uint32_t p = tid; p < old_size; p += S::T) {
+    const uint64_t c = l_old[p];
+    if (c == 0) continue;
+    mine++;
+    uint32_t cur = p, i = cell_key(c) & nmask;
+    for (;;) {
+      const uint32_t prev = atomicMin(&l_tab[i], cur);
+      if (prev == NONE) break;                       // the slot was free
+      if (prev > cur) cur = prev;                    // evicted a later cell: carry it onward
+      i = (i + 1) & nmask;
+    }
+  }
+  if (mine) atomicAdd(&l_cd[0], mine);
+  S::sync();
+  // a key that a probe from its home finds in ANOTHER slot first is a duplicate (grow_fixdup_one)
+  for (uint32_t q = tid; q < new_size; q += S::T) {
+    const uint32_t r = l_tab[q];
+    if (r == NONE) continue;
+    const uint32_t key = cell_key(l_old[r]);
+    uint32_t i = key & nmask;
+    while (i != q) {
+      const uint32_t r2 = l_tab[i];
+      if (r2 == NONE || cell_key(l_old[r2]) == key) break;
+      i = (i + 1) & nmask;
+    }
+    if (i != q) l_cd[1] = 1;
+  }
+  S::sync();
+  const uint32_t dup = l_cd[1];
+  if (!dup) {
+    for (uint32_t q = tid; q < new_size; q += S::T) {
+      const uint32_t r = l_tab[q];
+      T[q] = r == NONE ? 0ull : l_old[r];
+    }
+    for (uint32_t p = tid; p < old_size; p += S::T) O[p] = 0;
+  }
+  if (tid == 0) {
+    task->count = l_cd[0];
+    task->dup = dup;                                 // the redo reads the (intact) old block
+  }
+  S::sync();
+}
+
+// one workgroup (THREADS = 64: one wave) per task of the given kind
 template <int THREADS, uint32_t MAX_LG>
 __global__ __launch_bounds__(THREADS) void k_grow_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
                                                       uint32_t kind, uint8_t* arena) {
-  extern __shared__ uint64_t l_old[];                               // 2^MAX_LG cells ...
-  uint32_t* l_tab = reinterpret_cast<uint32_t*>(l_old + (1u << MAX_LG));   // ... and 2^(MAX_LG+1) slot indices
-  __shared__ uint32_t l_cnt, l_dup;
-  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  extern __shared__ uint64_t l_dyn[];                               // 2^MAX_LG cells ...
+  uint32_t* l_tab = reinterpret_cast<uint32_t*>(l_dyn + (1u << MAX_LG));   // ... and 2^(MAX_LG+1) slot indices
+  __shared__ uint32_t l_cd[2];
   const uint32_t n = ctl->n_kind[kind];
-  for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {                   // block-uniform
-    const uint32_t t = list[li];
-    const uint32_t old_lg = tasks[t].old_lg;
-    const uint32_t old_size = 1u << old_lg, new_size = 2u << old_lg, nmask = new_size - 1u;
-    uint64_t* O = row_cells(arena, tasks[t].old_base);
-    uint64_t* T = row_cells(arena, tasks[t].new_base);
-    if (threadIdx.x == 0) { l_cnt = 0; l_dup = 0; }
-    for (uint32_t q = threadIdx.x; q < new_size; q += THREADS) l_tab[q] = NONE;
-    for (uint32_t p = threadIdx.x; p < old_size; p += THREADS) l_old[p] = O[p];
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t p = threadIdx.x; p < old_size; p += THREADS) {
-      const uint64_t c = l_old[p];
-      if (c == 0) continue;
-      mine++;
-      uint32_t cur = p, i = cell_key(c) & nmask;
-      for (;;) {
-        const uint32_t prev = atomicMin(&l_tab[i], cur);
-        if (prev == NONE) break;                     // the slot was free
-        if (prev > cur) cur = prev;                  // evicted a later cell: carry it onward
-        i = (i + 1) & nmask;
-      }
-    }
-    if (mine) atomicAdd(&l_cnt, mine);
-    __syncthreads();
-    // a key that a probe from its home finds in ANOTHER slot first is a duplicate (k_grow_fixdup)
-    for (uint32_t q = threadIdx.x; q < new_size; q += THREADS) {
-      const uint32_t r = l_tab[q];
-      if (r == NONE) continue;
-      const uint32_t key = cell_key(l_old[r]);
-      uint32_t i = key & nmask;
-      while (i != q) {
-        const uint32_t r2 = l_tab[i];
-        if (r2 == NONE || cell_key(l_old[r2]) == key) break;
-        i = (i + 1) & nmask;
-      }
-      if (i != q) l_dup = 1;
-    }
-    __syncthreads();
-    const uint32_t dup = l_dup;
-    if (!dup) {
-      for (uint32_t q = threadIdx.x; q < new_size; q += THREADS) {
-        const uint32_t r = l_tab[q];
-        T[q] = r == NONE ? 0ull : l_old[r];
-      }
-      for (uint32_t p = threadIdx.x; p < old_size; p += THREADS) O[p] = 0;
-    }
-    if (threadIdx.x == 0) {
-      tasks[t].count = l_cnt;
-      tasks[t].dup = dup;                            // fixdup redoes the row from the (intact) old block
-    }
-    __syncthreads();
-  }
+  for (uint32_t li = blockIdx.x; li < n; li += gridDim.x)                     // block-uniform
+    grow_lds_task<BlockScope<THREADS>>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd);
 }
 
 // one wave per 64 old slots
-__global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tasks,
-                                                   const uint32_t* map_old, uint8_t* arena) {
-  uint32_t nchunks = ctl->n_chunks;
-  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void grow_move_body(VGrid g, const Ctl* ctl, GrowTask* tasks,
+                                               const uint32_t* map_old, uint8_t* arena) {
+  uint32_t nchunks = aload(&ctl->n_chunks);
+  uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
     uint32_t t = map_old[ch];
     GrowTask& k = tasks[t];
@@ -926,14 +982,18 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
     }
   }
 }
+__global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tasks,
+                                                   const uint32_t* map_old, uint8_t* arena) {
+  grow_move_body(SMX_VG, ctl, tasks, map_old, arena);
+}
 
 // one wave per 64 new slots: replace the carried old-slot index by the value
-__global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* tasks,
-                                                     const uint32_t* map_new, uint8_t* arena) {
-  uint32_t nchunks = ctl->n_chunks_new;
-  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTask* tasks,
+                                                 const uint32_t* map_new, uint8_t* arena) {
+  uint32_t nchunks = aload(&ctl->n_chunks_new);
+  uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
     uint32_t t = map_new[ch];
     const GrowTask k = tasks[t];
@@ -954,6 +1014,10 @@ __global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* t
     }
   }
 }
+__global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* tasks,
+                                                     const uint32_t* map_new, uint8_t* arena) {
+  grow_finish_body(SMX_VG, ctl, tasks, map_new, arena);
+}
 
 // A row table can hold one key twice: y=0 writes may turn the uncounted (0,v) cell back
 // into an empty one (quirk Q1/Q3) and so cut a probe chain, after which the key behind the
@@ -961,54 +1025,54 @@ __global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* t
 // smatrix_rmap_resize merges such twins -- the second one finds the first through
 // rmap_insert, keeps its slot and overwrites its value (src/smatrix.c:353-357,:401-402).
 // Priority probing cannot express the merge, so these (rare) rows are redone here the
-// reference's way: one lane, old slot order.
-__global__ void k_grow_fixdup(const Ctl* ctl, GrowTask* tasks, uint8_t* arena) {
-  uint32_t n = ctl->n_tasks;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
-    GrowTask& k = tasks[t];
-    if (!k.dup) continue;
-    const uint32_t old_size = 1u << k.old_lg, nmask = 2u * old_size - 1u;
-    const uint64_t* O = row_cells(arena, k.old_base);
-    uint64_t* T = row_cells(arena, k.new_base);
-    for (uint32_t q = 0; q <= nmask; q++) T[q] = 0;
-    uint32_t used = 0;
-    for (uint32_t p = 0; p < old_size; p++) {
-      const uint64_t c = O[p];
-      if (c == 0) continue;
-      const uint32_t key = cell_key(c);
-      uint32_t i = key & nmask;
-      while (cell_key(T[i]) != key && T[i] != 0) i = (i + 1) & nmask;   // :363-380
-      if (cell_key(T[i]) == 0 || cell_key(T[i]) != key) used++;          // :353-354
-      T[i] = c;
-    }
-    k.count = used;
-    if (grow_kind(k.old_lg) != GROW_CHUNKED)         // k_grow_lds left the old block for this redo
-      for (uint32_t p = 0; p < old_size; p++) row_cells(arena, k.old_base)[p] = 0;
+// reference's way: one lane, old slot order.  The old block is left zeroed, like the other paths
+// leave it (k_grow_lds / k_grow_zero skip rows marked dup).
+__device__ inline void grow_fixdup_one(GrowTask& k, uint8_t* arena) {
+  const uint32_t old_size = 1u << k.old_lg, nmask = 2u * old_size - 1u;
+  uint64_t* O = row_cells(arena, k.old_base);
+  uint64_t* T = row_cells(arena, k.new_base);
+  for (uint32_t q = 0; q <= nmask; q++) T[q] = 0;
+  uint32_t used = 0;
+  for (uint32_t p = 0; p < old_size; p++) {
+    const uint64_t c = O[p];
+    if (c == 0) continue;
+    const uint32_t key = cell_key(c);
+    uint32_t i = key & nmask;
+    while (cell_key(T[i]) != key && T[i] != 0) i = (i + 1) & nmask;   // :363-380
+    if (cell_key(T[i]) == 0 || cell_key(T[i]) != key) used++;          // :353-354
+    T[i] = c;
   }
+  k.count = used;
+  for (uint32_t p = 0; p < old_size; p++) O[p] = 0;
 }
 
 // one wave per 64 old slots: a retired block goes back to its size class's stack ZEROED
 // (row creation and growth rely on fresh blocks being all-empty)
-__global__ __launch_bounds__(256) void k_grow_zero(const Ctl* ctl, const GrowTask* tasks,
-                                                   const uint32_t* map_old, uint8_t* arena) {
-  uint32_t nchunks = ctl->n_chunks;
-  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void grow_zero_body(VGrid g, const Ctl* ctl, const GrowTask* tasks,
+                                               const uint32_t* map_old, uint8_t* arena) {
+  uint32_t nchunks = aload(&ctl->n_chunks);
+  uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
     const GrowTask k = tasks[map_old[ch]];
+    if (k.dup) continue;                             // grow_fixdup_one still needs (and then zeroes) it
     const uint32_t p = (ch - k.chunk0) * 64 + lane;
     if (p < (1u << k.old_lg)) row_cells(arena, k.old_base)[p] = 0;
   }
 }
+__global__ __launch_bounds__(256) void k_grow_zero(const Ctl* ctl, const GrowTask* tasks,
+                                                   const uint32_t* map_old, uint8_t* arena) {
+  grow_zero_body(SMX_VG, ctl, tasks, map_old, arena);
+}
 
 // publish the new tables (src/smatrix.c:408-410) and push the old blocks on their classes' stacks
 // (one atomic per class and workgroup; the host sized every stack for this round's pushes beforehand)
-__global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, const GrowTask* tasks, DirSlot* dir, uint8_t* arena,
-                                                     FreeLists fl) {
+__device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* tasks, DirSlot* dir, uint8_t* arena,
+                                                 FreeLists fl) {
   __shared__ uint32_t l_want[N_CLASSES], l_at[N_CLASSES];
-  const uint32_t n = ctl->n_tasks;
-  for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < n; t0 += gridDim.x * blockDim.x) {    // block-uniform
+  const uint32_t n = aload(&ctl->n_tasks);
+  for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t t = t0 + threadIdx.x;
@@ -1016,11 +1080,12 @@ __global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, const GrowTask* t
     GrowTask k = {};
     uint32_t cls = 0, rank = 0;
     if (live) {
+      if (tasks[t].dup) grow_fixdup_one(tasks[t], arena);
       k = tasks[t];
       DirSlot& d = dir[k.dslot];
       const uint32_t lg = k.old_lg + 1;
       uint32_t count = k.count;
-      if (lg >= BIG_LG && !k.dup) {                     // k_grow_move's sharded count (fixdup recounts itself)
+      if (lg >= BIG_LG && !k.dup) {                     // k_grow_move's sharded count (the redo recounts itself)
         const SubCtr* sc = row_subs(arena, k.new_base, lg);
         for (uint32_t i = 0; i < SUBS; i++) count += sc[i].cnt;
       }
@@ -1048,11 +1113,15 @@ __global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, const GrowTask* t
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, GrowTask* tasks, DirSlot* dir, uint8_t* arena,
+                                                     FreeLists fl) {
+  grow_commit_body(SMX_VG, ctl, tasks, dir, arena, fl);
+}
 
 // big rows flagged by prep: fold the sub-counters into `used`, share out what room is left
-__global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uint8_t* arena) {
-  uint32_t n = ctl->n_rebal;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+__device__ __forceinline__ void rebal_body(VGrid g, const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uint8_t* arena) {
+  uint32_t n = aload(&ctl->n_rebal);
+  for (uint32_t t = g.bid * blockDim.x + threadIdx.x; t < n; t += g.nb * blockDim.x) {
     DirSlot& d = dir[rebal[t]];
     const uint32_t lg = meta_lg(d.meta);
     SubCtr* sc = row_subs(arena, d.base, lg);
@@ -1063,6 +1132,9 @@ __global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uin
     d.meta &= ~META_REBAL;
     subs_init(sc, cap > used ? cap - used : 0u);
   }
+}
+__global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uint8_t* arena) {
+  rebal_body(SMX_VG, ctl, rebal, dir, arena);
 }
 
 // ---- set: duplicates of one cell inside a batch resolve highest-index-wins ----

@@ -379,8 +379,6 @@ void grow_rows(Matrix* m, hipStream_t s) {
     hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
                        dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
   }
-  hipLaunchKernelGGL(k_grow_fixdup, dim3(std::min<uint32_t>(blocks_for(nt, 64), 1024)), dim3(64), 0, s,
-                     m->d_ctl, m->tasks.p, m->arena.base);
   if (n_chunked)
     hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                        dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
