@@ -53,7 +53,10 @@ __host__ __device__ inline uint64_t units_of_lg(uint32_t lg) { return 1ull << (l
 // than size/2+1 keys; `used` in the directory is the count at the last fold and
 //   rowlen = used + sum(cnt)   at any quiescent point.
 constexpr uint32_t META_REBAL = 1u << 17;  // quotas want re-partitioning (k_rebal)
-constexpr uint32_t BIG_LG = 15;
+#ifndef SMX_BIG_LG
+#define SMX_BIG_LG 15
+#endif
+constexpr uint32_t BIG_LG = SMX_BIG_LG;
 constexpr uint32_t SUBS = 64;     // 4 KB per big row (>= 256 KB of cells)
 constexpr uint32_t SUB_UNITS = SUBS * 64 / 128;
 struct SubCtr { uint32_t cnt, quota, pad[14]; };
@@ -323,7 +326,23 @@ __device__ __forceinline__ void apply_body(
       uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
       if (!deferred) out[j] = r;
     }
-    if (OP != OP_GET) list_push(&ctl->n_defer, defer, j, deferred);
+    if (OP != OP_GET) {
+      // one list reservation per WORKGROUP: every atomic instruction on this one word queues at the
+      // memory side (~34 ns each), and a retry round has thousands of waves with a deferred op
+      __shared__ uint32_t l_n, l_base;
+      if (!__syncthreads_or(deferred)) continue;
+      if (threadIdx.x == 0) l_n = 0;
+      __syncthreads();
+      const uint64_t m = __ballot(deferred);
+      const uint32_t lane = __lane_id();
+      uint32_t wbase = 0;
+      if (m && lane == 0) wbase = atomicAdd(&l_n, (uint32_t)__popcll(m));
+      wbase = __shfl(wbase, 0);
+      __syncthreads();
+      if (threadIdx.x == 0) l_base = atomicAdd(&ctl->n_defer, l_n);
+      __syncthreads();
+      if (deferred) defer[l_base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+    }
   }
 }
 
