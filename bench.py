@@ -209,10 +209,20 @@ def main():
     dt = time.perf_counter() - t0
     st = local_m.stats()
     local_m.profile(False)
+    shard_info = None
     if sharded:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # how evenly the placement spread the ops (ops each shard applied over the whole run / mean)
+        loads = [None] * world
+        dist.all_gather_object(loads, int(m.exchanged_ops))
+        mean = max(sum(loads) / world, 1)
+        shard_info = {"rows_placed_by_load": len(m.placement.place),
+                      "hash_range_widths": ([round((b - a) / 2.0 ** 32, 4) for a, b in
+                                             zip([0] + m.placement.cuts, m.placement.cuts + [1 << 32])]
+                                            if m.placement.cuts is not None else "equal"),
+                      "ops_applied_over_mean": [round(v / mean, 3) for v in loads]}
 
     # informative extra (not `value`): the same step on the finished table -- every incr is a hit
     steady = None
@@ -242,6 +252,8 @@ def main():
                    "batch_ops": B, "distinct_batches": ring, "parallelism": "row-hash shards x%d" % world if sharded else "single GPU"},
         "sanity_all_gets_positive": ok,
     }
+    if shard_info:
+        res["config"]["placement"] = shard_info
     if rank == 0:
         ki = st["kernel_ms_incr"] / max(st["kernel_launches_incr"], 1)
         kg = st["kernel_ms_get"] / max(st["kernel_launches_get"], 1)

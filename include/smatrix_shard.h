@@ -14,25 +14,45 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "smatrix.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-/* owner shard of row x: floor(mix(x) * nshards / 2^32), nshards <= 64 */
+/* hash owner of row x: floor(mix(x) * nshards / 2^32), nshards <= 64 */
 uint32_t smatrix_shard_of(uint32_t x, uint32_t nshards);
+
+/* PLACEMENT (optional; planned by the caller, libsmatrix_amd/sharded.py).  Under Zipf the hottest row
+ * alone is 12 % of all ops, so equal hash ranges leave its owner with 1.9x the mean load of 8 shards.
+ *   d_cuts  : nshards - 1 ascending cut points of the hash space (device memory): shard r owns the rows
+ *             with cuts[r-1] <= smatrix_shard_mix(x) < cuts[r] (cuts[-1] = 0, cuts[nshards-1] = 2^32).
+ *             NULL = equal ranges = smatrix_shard_of.
+ *   d_place : the few hot rows placed one by one: `place_slots` (a power of two <= 1024, or 0 for none)
+ *             entries {x, owner + 1} in device memory, open addressing, slot of x =
+ *             smatrix_place_slot(x, place_slots), linear probing, owner + 1 == 0 marks an empty slot.
+ * A row's owner is its d_place entry if it has one, else the range its hash falls in. */
+uint32_t smatrix_shard_mix(uint32_t x);
+uint32_t smatrix_place_slot(uint32_t x, uint32_t place_slots);
+
+/* rows held by this matrix whose EQUAL-RANGE hash owner is not `rank` (lets files written without a
+ * stored placement be reopened).  Writes up to cap ids to out_x (host); returns how many there are. */
+size_t smatrix_displaced_rows(smatrix_t* self, uint32_t rank, uint32_t nshards, uint32_t* out_x, size_t cap);
 
 /* Reorders the n ops shard by shard.  counts_host[s] (host) = ops owned by shard s;
  * d_perm[i] = position of op i in the reordered arrays d_xo/d_yo/d_vo (d_v, d_vo may be NULL);
  * d_work: >= 512 bytes of device scratch.  Synchronises hip_stream.  Returns 0 on success. */
 int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                           uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
-                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream);
+                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, const uint32_t* d_place,
+                          uint32_t place_slots, const uint32_t* d_cuts, void* hip_stream);
 
 /* Same, but the reordered ops are written as one record {x,y,v} (d_v != NULL, width 3) or {x,y}
  * (width 2) per op into d_packed, so that a single all-to-all moves them. */
 int smatrix_partition_packed_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                                  uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
-                                 uint32_t* d_packed, void* hip_stream);
+                                 uint32_t* d_packed, const uint32_t* d_place, uint32_t place_slots,
+                                 const uint32_t* d_cuts, void* hip_stream);
 
 /* records of `width` words -> separate x/y[/v] arrays (the form the op kernels consume) */
 int smatrix_unpack_dev(size_t n, uint32_t width, const uint32_t* d_packed, uint32_t* d_x, uint32_t* d_y,

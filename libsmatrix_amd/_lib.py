@@ -70,8 +70,11 @@ def load():
         "smatrix_device_available": (C.c_int, []),
         # include/smatrix_shard.h
         "smatrix_shard_of": (C.c_uint32, [C.c_uint32, C.c_uint32]),
-        "smatrix_partition_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V, V, V]),
-        "smatrix_partition_packed_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V]),
+        "smatrix_partition_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V, V, V, C.c_uint32, V, V]),
+        "smatrix_partition_packed_dev": (C.c_int, [C.c_size_t, V, V, V, C.c_uint32, u64p, V, V, V, V, C.c_uint32, V, V]),
+        "smatrix_shard_mix": (C.c_uint32, [C.c_uint32]),
+        "smatrix_place_slot": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+        "smatrix_displaced_rows": (C.c_size_t, [V, C.c_uint32, C.c_uint32, V, C.c_size_t]),
         "smatrix_unpack_dev": (C.c_int, [C.c_size_t, C.c_uint32, V, V, V, V, V]),
         "smatrix_gather_dev": (C.c_int, [C.c_size_t, V, V, V, V]),
         # include/smx_probe.h

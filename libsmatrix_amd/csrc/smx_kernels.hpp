@@ -1409,14 +1409,50 @@ __host__ __device__ inline uint32_t shard_of(uint32_t x, uint32_t nshards) {
 
 constexpr uint32_t MAX_SHARDS = 64;
 
+// Placement (libsmatrix_amd/sharded.py plans it, include/smatrix_shard.h states the layout):
+//   cuts  : nshards - 1 ascending cut points of the 32-bit hash space; shard r owns the rows with
+//           cuts[r-1] <= shard_mix(x) < cuts[r]  (cuts[-1] = 0, cuts[nshards-1] = 2^32).  NULL = equal ranges.
+//   place : the few hot rows that are placed one by one: open addressing over `slots` (a power of two
+//           <= PLACE_MAX_SLOTS) entries {x, owner + 1}; slot of x = fmix32(x) & (slots - 1), linear
+//           probing, owner + 1 == 0 marks an empty slot.
+constexpr uint32_t PLACE_MAX_SLOTS = 1024;
+struct PlaceLds {
+  uint2 tab[PLACE_MAX_SLOTS];
+  uint32_t cuts[MAX_SHARDS];
+};
+__device__ inline void place_stage(PlaceLds& l, const uint2* place, uint32_t slots, const uint32_t* cuts, uint32_t nshards) {
+  for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) l.tab[i] = place[i];
+  if (cuts && threadIdx.x < nshards - 1u) l.cuts[threadIdx.x] = cuts[threadIdx.x];
+}
+__device__ inline uint32_t owner_of(uint32_t x, uint32_t nshards, const PlaceLds& l, uint32_t slots, bool have_cuts) {
+  if (slots) {
+    for (uint32_t i = fmix32(x) & (slots - 1u);; i = (i + 1u) & (slots - 1u)) {
+      const uint2 e = l.tab[i];
+      if (e.y == 0) break;
+      if (e.x == x) return e.y - 1u;
+    }
+  }
+  if (!have_cuts) return shard_of(x, nshards);
+  const uint32_t h = shard_mix(x);
+  uint32_t lo = 0, hi = nshards - 1u;             // owner = number of cut points <= h
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (l.cuts[mid] <= h) lo = mid + 1u; else hi = mid;
+  }
+  return lo;
+}
+
 // pass 1: per-shard op counts (LDS histogram per workgroup, one global atomic per shard per WG)
 __global__ __launch_bounds__(256) void k_part_count(uint32_t n, const uint32_t* __restrict__ xs,
-                                                    uint32_t nshards, unsigned long long* counts) {
+                                                    uint32_t nshards, unsigned long long* counts,
+                                                    const uint2* place, uint32_t place_slots, const uint32_t* cuts) {
   __shared__ uint32_t h[MAX_SHARDS];
+  __shared__ PlaceLds l_place;
   if (threadIdx.x < MAX_SHARDS) h[threadIdx.x] = 0;
+  place_stage(l_place, place, place_slots, cuts, nshards);
   __syncthreads();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    atomicAdd(&h[shard_of(xs[i], nshards)], 1u);
+    atomicAdd(&h[owner_of(xs[i], nshards, l_place, place_slots, cuts != nullptr)], 1u);
   __syncthreads();
   if (threadIdx.x < nshards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
@@ -1429,10 +1465,13 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     uint32_t n, const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t nshards, unsigned long long* cursors,
     uint32_t* __restrict__ perm, uint32_t* __restrict__ xo, uint32_t* __restrict__ yo,
-    uint32_t* __restrict__ vo, uint32_t* __restrict__ packed) {
+    uint32_t* __restrict__ vo, uint32_t* __restrict__ packed, const uint2* place, uint32_t place_slots,
+    const uint32_t* cuts) {
   __shared__ uint32_t cnt[MAX_SHARDS];
   __shared__ unsigned long long base[MAX_SHARDS];
+  __shared__ PlaceLds l_place;
   if (threadIdx.x < MAX_SHARDS) cnt[threadIdx.x] = 0;
+  place_stage(l_place, place, place_slots, cuts, nshards);
   __syncthreads();
   const uint32_t tile0 = blockIdx.x * 256 * PART_OPT;
   uint32_t sh[PART_OPT], rk[PART_OPT], X[PART_OPT];
@@ -1442,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     sh[k] = ~0u;
     if (i < n) {
       X[k] = xs[i];
-      sh[k] = shard_of(X[k], nshards);
+      sh[k] = owner_of(X[k], nshards, l_place, place_slots, cuts != nullptr);
       rk[k] = atomicAdd(&cnt[sh[k]], 1u);
     }
   }
@@ -1465,6 +1504,19 @@ __global__ __launch_bounds__(256) void k_part_scatter(
       xo[dst] = X[k];
       yo[dst] = ys[i];
       if (vs) vo[dst] = vs[i];
+    }
+  }
+}
+
+// rows of this shard whose hash owner is another shard (the placement table is rebuilt from them when
+// sharded files are reopened)
+__global__ __launch_bounds__(256) void k_displaced_rows(const DirSlot* dir, uint32_t dir_size, uint32_t rank,
+                                                        uint32_t nshards, uint32_t* out, uint32_t cap, uint32_t* count) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < dir_size; i += gridDim.x * blockDim.x) {
+    const DirSlot d = dir[i];
+    if ((d.meta & META_USED) && shard_of(d.x, nshards) != rank) {   // (equal ranges: files written without a placement)
+      const uint32_t k = atomicAdd(count, 1u);
+      if (k < cap) out[k] = d.x;
     }
   }
 }

@@ -952,14 +952,16 @@ uint32_t smatrix_shard_of(uint32_t x, uint32_t nshards) { return shard_of(x, nsh
 static int partition_impl(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                           uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
                           uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, uint32_t* d_packed,
-                          void* hip_stream) {
+                          const uint32_t* d_place, uint32_t place_slots, const uint32_t* d_cuts, void* hip_stream) {
   if (nshards == 0 || nshards > MAX_SHARDS || n >= (1ull << 32)) return -1;
+  if (place_slots > PLACE_MAX_SLOTS || (place_slots & (place_slots - 1)) || (place_slots && !d_place)) return -1;
+  const uint2* place = reinterpret_cast<const uint2*>(d_place);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   unsigned long long* work = static_cast<unsigned long long*>(d_work);   // >= 64 * 8 bytes
   HIP_OK(hipMemsetAsync(work, 0, MAX_SHARDS * sizeof(unsigned long long), s));
   if (n) {
     hipLaunchKernelGGL(k_part_count, dim3(std::min<uint32_t>(blocks_for(n), 2048)), dim3(256), 0, s,
-                       (uint32_t)n, d_x, nshards, work);
+                       (uint32_t)n, d_x, nshards, work, place, place_slots, d_cuts);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipMemcpyAsync(counts_host, work, nshards * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -969,7 +971,7 @@ static int partition_impl(size_t n, const uint32_t* d_x, const uint32_t* d_y, co
   HIP_OK(hipMemcpyAsync(work, cur, nshards * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
   if (n) {
     hipLaunchKernelGGL(k_part_scatter, dim3(blocks_for(n, 256 * PART_OPT)), dim3(256), 0, s, (uint32_t)n,
-                       d_x, d_y, d_v, nshards, work, d_perm, d_xo, d_yo, d_vo, d_packed);
+                       d_x, d_y, d_v, nshards, work, d_perm, d_xo, d_yo, d_vo, d_packed, place, place_slots, d_cuts);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(s));   // `cur` lives on this stack frame
@@ -978,16 +980,41 @@ static int partition_impl(size_t n, const uint32_t* d_x, const uint32_t* d_y, co
 
 int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                           uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
-                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, void* hip_stream) {
+                          uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, const uint32_t* d_place,
+                          uint32_t place_slots, const uint32_t* d_cuts, void* hip_stream) {
   return partition_impl(n, d_x, d_y, d_v, nshards, counts_host, d_work, d_perm, d_xo, d_yo, d_vo, nullptr,
-                        hip_stream);
+                        d_place, place_slots, d_cuts, hip_stream);
 }
 
 int smatrix_partition_packed_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                                  uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
-                                 uint32_t* d_packed, void* hip_stream) {
+                                 uint32_t* d_packed, const uint32_t* d_place, uint32_t place_slots,
+                                 const uint32_t* d_cuts, void* hip_stream) {
   return partition_impl(n, d_x, d_y, d_v, nshards, counts_host, d_work, d_perm, nullptr, nullptr, nullptr,
-                        d_packed, hip_stream);
+                        d_packed, d_place, place_slots, d_cuts, hip_stream);
+}
+
+uint32_t smatrix_place_slot(uint32_t x, uint32_t slots) { return smx_fmix32(x) & (slots - 1u); }
+uint32_t smatrix_shard_mix(uint32_t x) { return shard_mix(x); }
+
+size_t smatrix_displaced_rows(smatrix_t* self, uint32_t rank, uint32_t nshards, uint32_t* out_x, size_t cap) {
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  uint32_t *d_out = nullptr, *d_cnt = nullptr;
+  const uint32_t c = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+  HIP_OK(hipMalloc(&d_out, std::max<size_t>(c, 1) * 4));
+  HIP_OK(hipMalloc(&d_cnt, 4));
+  HIP_OK(hipMemsetAsync(d_cnt, 0, 4, m->stream));
+  hipLaunchKernelGGL(k_displaced_rows, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, m->stream,
+                     m->d_dir, m->dir_size, rank, nshards, d_out, c, d_cnt);
+  HIP_OK(hipGetLastError());
+  uint32_t cnt = 0;
+  HIP_OK(hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_OK(hipStreamSynchronize(m->stream));
+  if (out_x && std::min<uint32_t>(cnt, c)) HIP_OK(hipMemcpy(out_x, d_out, (size_t)std::min<uint32_t>(cnt, c) * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_out); (void)hipFree(d_cnt);
+  return cnt;
 }
 
 int smatrix_unpack_dev(size_t n, uint32_t width, const uint32_t* d_packed, uint32_t* d_x, uint32_t* d_y,

@@ -17,7 +17,9 @@ The two device-side pieces are injectable so that the routing logic can be exerc
 CPU with gloo (tests/test_sharded_gloo.py supplies a CPU partitioner and an oracle-backed
 shard); the defaults are the HIP implementations and fail loudly without a GPU.
 """
+import bisect
 import ctypes as C
+import json
 import os
 
 import torch
@@ -31,11 +33,83 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class Placement:
+    """Which shard owns a row: `place` {x: owner} for the few hot rows placed one by one, else the hash
+    range that smatrix_shard_mix(x) falls in (`cuts`: world-1 ascending cut points, None = equal ranges)."""
+
+    def __init__(self, world, cuts=None, place=None):
+        self.world, self.cuts, self.place = world, cuts, dict(place or {})
+
+    def owner(self, x, lib=None):
+        x = int(x) & 0xFFFFFFFF
+        if x in self.place:
+            return self.place[x]
+        lib = lib or _lib.load()
+        if self.cuts is None:
+            return lib.smatrix_shard_of(x, self.world)
+        return bisect.bisect_right(self.cuts, lib.smatrix_shard_mix(x))
+
+    def to_json(self):
+        return json.dumps({"world": self.world, "cuts": self.cuts,
+                           "place": sorted([int(k), int(v)] for k, v in self.place.items())})
+
+    @staticmethod
+    def from_json(text):
+        d = json.loads(text)
+        return Placement(d["world"], d["cuts"], {int(k): int(v) for k, v in d["place"]})
+
+
+def plan_placement(counts, total, world, top=256):
+    """Skew-aware placement (SURVEY.md 8e "skew handling").  counts: {x: ops seen} for the hottest rows of a
+    sample of `total` ops.  Under Zipf(1.1) the hottest row is 12.4 % of all ops: with equal hash ranges its
+    owner carries 23 % of the load of 8 shards (1.9x the mean).  Here
+      1. the `top` hottest rows are assigned one by one, longest processing time first, to the least
+         loaded shard;
+      2. the remaining rows -- a flat tail, so a shard's share of it is the width of its hash range -- are
+         given RANGES OF UNEQUAL WIDTH that fill every shard up to the same level (a shard already full
+         of hot rows gets an empty range).
+    Deterministic: every rank computes the same plan from the same gathered counts.  -> Placement"""
+    hot = sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))[:top]
+    load = [0] * world
+    owner = {}
+    for x, c in hot:
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += c
+        owner[x] = r
+    tail = max(total - sum(c for _, c in hot), 0)
+    # water level L with sum(max(L - load, 0)) == tail
+    order = sorted(load)
+    level, acc = float(order[-1]) + tail, 0.0          # fallback, overwritten below
+    for k in range(1, world + 1):                      # the k least loaded shards share the tail
+        acc = sum(order[:k])
+        level = (tail + acc) / k
+        if k == world or level <= order[k]:
+            break
+    width = [max(level - l, 0.0) for l in load]
+    tot_w = sum(width) or 1.0
+    cuts, run = [], 0.0
+    for r in range(world - 1):
+        run += width[r] / tot_w
+        cuts.append(min(int(run * 4294967296.0), 0xFFFFFFFF))
+    return Placement(world, cuts, owner)
+
+
 class HipShard:
     """The local shard: a SparseMatrix driven with device pointers on torch's current stream."""
 
     def __init__(self, filename=None):
         self.m = SparseMatrix(filename)
+
+    def row_count(self):
+        return int(self.m.stats()["rows"])
+
+    def displaced_rows(self, rank, world):
+        """rows held here whose hash owner is another shard"""
+        lib = _lib.load()
+        n = lib.smatrix_displaced_rows(self.m._h, rank, world, None, 0)
+        buf = (C.c_uint32 * max(n, 1))()
+        n = min(lib.smatrix_displaced_rows(self.m._h, rank, world, C.cast(buf, C.c_void_p), n), n)
+        return [int(buf[i]) for i in range(n)]
 
     def apply(self, op, x, y, v, out):
         n = x.numel()
@@ -56,7 +130,38 @@ class HipPartitioner:
 
     def __init__(self, device):
         self.lib = _lib.load()
+        self.device = device
         self.work = torch.zeros(128, dtype=torch.int64, device=device)
+        self.place = None           # device table [slots, 2] int32 {x, owner + 1}, see include/smatrix_shard.h
+        self.place_slots = 0
+        self.cuts = None            # device array of world-1 cut points
+
+    def set_placement(self, pl):
+        """pl: Placement (or None for equal hash ranges)"""
+        self.place, self.place_slots, self.cuts = None, 0, None
+        if pl is None:
+            return
+        i32 = lambda u: u - (1 << 32) if u >= (1 << 31) else u
+        if pl.cuts is not None and pl.world > 1:
+            self.cuts = torch.tensor([i32(c) for c in pl.cuts], dtype=torch.int32, device=self.device)
+        if pl.place:
+            slots = 16
+            while slots < 2 * len(pl.place):
+                slots *= 2
+            if slots > 1024:
+                raise ValueError("placement table too large (%d rows)" % len(pl.place))
+            tab = [[0, 0] for _ in range(slots)]
+            for x, owner in pl.place.items():
+                i = self.lib.smatrix_place_slot(x, slots)
+                while tab[i][1]:
+                    i = (i + 1) & (slots - 1)
+                tab[i] = [i32(x), owner + 1]
+            self.place = torch.tensor(tab, dtype=torch.int32, device=self.device)
+            self.place_slots = slots
+
+    def _place_args(self):
+        return (self.place.data_ptr() if self.place is not None else None, self.place_slots,
+                self.cuts.data_ptr() if self.cuts is not None else None)
 
     def partition(self, x, y, v, world):
         n = x.numel()
@@ -67,7 +172,7 @@ class HipPartitioner:
         rc = self.lib.smatrix_partition_dev(
             n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None, world,
             C.cast(counts, _lib.u64p), self.work.data_ptr(), perm.data_ptr(), xo.data_ptr(), yo.data_ptr(),
-            vo.data_ptr() if vo is not None else None, _stream())
+            vo.data_ptr() if vo is not None else None, *self._place_args(), _stream())
         if rc:
             raise RuntimeError("smatrix_partition_dev failed")
         return [int(c) for c in counts], perm, xo, yo, vo
@@ -80,7 +185,8 @@ class HipPartitioner:
         packed = torch.empty((n, 3 if v is not None else 2), dtype=torch.int32, device=x.device)
         rc = self.lib.smatrix_partition_packed_dev(
             n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None, world,
-            C.cast(counts, _lib.u64p), self.work.data_ptr(), perm.data_ptr(), packed.data_ptr(), _stream())
+            C.cast(counts, _lib.u64p), self.work.data_ptr(), perm.data_ptr(), packed.data_ptr(),
+            *self._place_args(), _stream())
         if rc:
             raise RuntimeError("smatrix_partition_packed_dev failed")
         return [int(c) for c in counts], perm, packed
@@ -99,7 +205,12 @@ class HipPartitioner:
 
 
 class ShardedMatrix:
-    def __init__(self, group=None, shard=None, partitioner=None, device=None):
+    """auto_place: the first write batch of an EMPTY matrix is also the sample from which the placement is
+    planned (plan_placement: hot rows by load, the rest in hash ranges of unequal width); with shard files
+    it is stored next to them (<file>.placement) and read back on reopen.  Rows never move afterwards."""
+
+    def __init__(self, group=None, shard=None, partitioner=None, device=None, auto_place=True, hot_rows=256,
+                 placement_file=None):
         if not dist.is_initialized():
             raise RuntimeError("ShardedMatrix needs an initialised torch.distributed process group")
         self.group = group
@@ -112,6 +223,77 @@ class ShardedMatrix:
         self.exchanged_ops = 0
         self.packed = os.environ.get("SMATRIX_SHARD_PACKED", "1") != "0"   # one collective per op batch
         self.host_staged = os.environ.get("SMATRIX_SHARD_HOST_STAGED", "0") == "1"
+        self.auto_place = auto_place and os.environ.get("SMATRIX_SHARD_PLACE", "1") != "0"
+        self.hot_rows = hot_rows
+        self.placement = Placement(self.world)   # equal hash ranges until planned
+        self._placed = False
+        self._known_empty = False
+        self.placement_file = placement_file
+        if placement_file is None and getattr(getattr(self.shard, "m", None), "filename", None):
+            self.placement_file = self.shard.m.filename + ".placement"
+
+    # ---- placement ----------------------------------------------------------------------------
+    def _gather_obj(self, obj):
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _ensure_placement(self, x, write=True):
+        """COLLECTIVE, before a batch is routed, until settled: decide which shard owns which row.
+          * a placement stored next to the shard files -> that one (rows are where it put them);
+          * an EMPTY matrix -> planned from this first batch (plan_placement);
+          * rows but no stored placement (files written with equal ranges) -> equal ranges, plus whatever
+            rows are found away from their range."""
+        if self._placed:
+            return
+        if not (hasattr(self.shard, "row_count") and hasattr(self.part, "set_placement")):
+            self._placed = True
+            return
+        if self._known_empty:
+            if not write:
+                return                      # reads of an empty matrix find nothing wherever they are routed
+            stored, rows = [None] * self.world, [0] * self.world
+        else:
+            stored = None
+            if self.placement_file and os.path.exists(self.placement_file):
+                stored = open(self.placement_file).read()
+            stored = self._gather_obj(stored)
+            rows = self._gather_obj(self.shard.row_count())
+            if not sum(rows):
+                self._known_empty = True
+                if not write:
+                    return
+        self._placed = True
+        if any(t is not None for t in stored) and sum(rows):
+            text = next(t for t in stored if t is not None)
+            if any(t is not None and t != text for t in stored):
+                raise RuntimeError("the shards' stored placements differ")
+            pl = Placement.from_json(text)
+            if pl.world != self.world:
+                raise RuntimeError("stored placement is for %d shards, this group has %d" % (pl.world, self.world))
+        elif sum(rows):
+            place = {}
+            for r, xs in enumerate(self._gather_obj(self.shard.displaced_rows(self.rank, self.world))):
+                for v in xs:
+                    place[int(v)] = r
+            pl = Placement(self.world, None, place)
+        elif self.auto_place and self.world > 1:
+            if x.numel():
+                ux, cnt = torch.unique(x, return_counts=True)
+                top = torch.topk(cnt, min(self.hot_rows, ux.numel())).indices
+                mine = {int(a) & 0xFFFFFFFF: int(c) for a, c in zip(ux[top].tolist(), cnt[top].tolist())}
+            else:
+                mine = {}
+            counts, total = {}, 0
+            for part, n in self._gather_obj((mine, int(x.numel()))):
+                total += n
+                for a, c in part.items():
+                    counts[a] = counts.get(a, 0) + c
+            pl = plan_placement(counts, total, self.world, self.hot_rows)
+        else:
+            pl = Placement(self.world)
+        self.placement = pl
+        self.part.set_placement(pl)
 
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         """all_to_all_single; with SMATRIX_SHARD_HOST_STAGED=1 the payload is staged through host
@@ -129,12 +311,13 @@ class ShardedMatrix:
         return self.shard.m
 
     def owner(self, x):
-        return _lib.load().smatrix_shard_of(int(x), self.world)
+        return self.placement.owner(x)
 
     def apply_dev(self, op, x, y, v, out):
         """x, y, v, out: 1-D int32 tensors on this rank's device (v None for get).
         COLLECTIVE: every rank must call it with the same op (batch sizes may differ)."""
         vv = None if op == OP_GET else v
+        self._ensure_placement(x, op != OP_GET)
         packed_path = self.packed and hasattr(self.part, "partition_packed")
         if packed_path:
             counts, perm, po = self.part.partition_packed(x, y, vv, self.world)
@@ -171,6 +354,7 @@ class ShardedMatrix:
         """rowlen of arbitrary rows: routed to the owners like an op batch (rows are shard-local, so a
         scan of a rank's OWN rows -- local.rowlen_batch / local.getrow_batch -- needs no exchange at all).
         COLLECTIVE."""
+        self._ensure_placement(xs, False)
         counts, perm, xo, _, _ = self.part.partition(xs, xs, None, self.world)
         send = torch.tensor(counts, dtype=torch.int64, device=xs.device)
         recv = torch.empty(self.world, dtype=torch.int64, device=xs.device)
@@ -211,6 +395,7 @@ class ShardedMatrix:
         h.op, h.n, h.x_dev = op, x.numel(), x.device
         comm = self._comm(x)
         vv = None if op == OP_GET else v
+        self._ensure_placement(x, op != OP_GET)
         ctx = torch.cuda.stream(comm) if comm is not None else _null_ctx()
         if comm is not None:
             comm.wait_stream(torch.cuda.current_stream())         # inputs were produced on the compute stream
@@ -275,6 +460,9 @@ class ShardedMatrix:
         h.keep = None
 
     def close(self):
+        if self.placement_file and self._placed:
+            with open(self.placement_file, "w") as f:
+                f.write(self.placement.to_json())
         self.shard.close()
 
 

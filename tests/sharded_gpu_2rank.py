@@ -10,7 +10,7 @@ os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR, _lib
+from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
 from libsmatrix_amd.sharded import ShardedMatrix
 
 B, S = 1 << 18, 4
@@ -44,17 +44,46 @@ for s in range(S):
     torch.cuda.synchronize()
     assert torch.equal(og, dg), "rank %d step %d: sharded get != un-sharded get" % (rank, s)
     assert int((oi <= og).all()), "an incr return exceeds the value the following get saw"
-lib = _lib.load()
 rows = torch.unique(torch.cat([xs.reshape(-1)]))[:20000]
-owners = torch.tensor([lib.smatrix_shard_of(int(v) & 0xFFFFFFFF, world) for v in rows[:2000].tolist()])
+owners = torch.tensor([sm.owner(int(v)) for v in rows[:2000].tolist()])
 mine = rows[:2000][owners == rank]
 if mine.numel():
     l = torch.empty(mine.numel(), dtype=torch.int32, device=dev)
     sm.local.rowlen_batch_dev(mine.numel(), mine.contiguous().data_ptr(), l.data_ptr(), st); torch.cuda.synchronize()
     assert int((l > 0).all()), "an owned row is missing from the local shard"
+# skew-aware placement was planned from the first batch: hot rows placed one by one, unequal hash ranges
+assert sm.placement.place and sm.placement.cuts is not None
+share = torch.tensor([float(sm.exchanged_ops)]); tot_ops = share.clone(); dist.all_reduce(tot_ops)
+assert abs(float(share) * world / float(tot_ops) - 1.0) < 0.15, "shard load %.3f of the mean" % (float(share) * world / float(tot_ops))
 tot = torch.tensor([sm.local.stats()["rows"]]); dist.all_reduce(tot)
 assert int(tot) == direct.stats()["rows"], (int(tot), direct.stats()["rows"])
+# file-backed shards: close (files + stored placement), reopen, same answers, further writes land on the same owners
+import tempfile
+from libsmatrix_amd.sharded import HipShard
+d = [tempfile.mkdtemp(prefix="smx2r_") if rank == 0 else None]
+dist.broadcast_object_list(d, src=0)
+path = os.path.join(d[0], "shard%d.smx" % rank)
+fm = ShardedMatrix(shard=HipShard(path))
+oi = torch.empty(B, dtype=torch.int32, device=dev)
+fm.apply_dev(OP_INCR, xs[0], ys[0], ones, oi)
+want = torch.empty(B, dtype=torch.int32, device=dev)
+fm.apply_dev(OP_GET, xs[0], ys[0], None, want)
+pl_text = fm.placement.to_json()
+fm.close()
+assert os.path.exists(path + ".placement")
+fm = ShardedMatrix(shard=HipShard(path))
+got = torch.empty(B, dtype=torch.int32, device=dev)
+fm.apply_dev(OP_GET, xs[0], ys[0], None, got)
+assert fm.placement.to_json() == pl_text, "the stored placement was not taken over"
+assert torch.equal(got, want), "values differ after close / reopen of the shard files"
+fm.apply_dev(OP_INCR, xs[0], ys[0], ones, oi)
+fm.apply_dev(OP_GET, xs[0], ys[0], None, got)
+torch.cuda.synchronize()
+assert torch.equal(got, want * 2), "writes after the reopen did not reach the rows' owners"
+fm.close()
 dist.barrier()
 if rank == 0:
+    import shutil
+    shutil.rmtree(d[0], ignore_errors=True)
     print("SHARDED_2RANK_OK rows=%d" % int(tot))
 sm.close(); direct.close(); dist.destroy_process_group()

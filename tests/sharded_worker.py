@@ -17,19 +17,43 @@ from libsmatrix_amd.sharded import ShardedMatrix  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
-def shard_of_np(x, world):
-    """numpy restatement of shard_of() in smx_kernels.hpp (cross-checked against the library)"""
+def shard_mix_np(x):
+    """numpy restatement of shard_mix() in smx_kernels.hpp (cross-checked against the library)"""
     h = x.astype(np.uint32) ^ np.uint32(0x9E3779B9)
     h ^= h >> np.uint32(16); h = (h * np.uint32(0x85EBCA6B)).astype(np.uint32)
     h ^= h >> np.uint32(13); h = (h * np.uint32(0xC2B2AE35)).astype(np.uint32)
     h ^= h >> np.uint32(16)
-    return ((h.astype(np.uint64) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+    return h
+
+
+def shard_of_np(x, world):
+    return ((shard_mix_np(x).astype(np.uint64) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+
+
+def owner_np(x, world, pl):
+    """owner of every row id under a Placement (None = equal hash ranges)"""
+    if pl is None or pl.cuts is None:
+        own = shard_of_np(x, world)
+    else:
+        own = np.searchsorted(np.array(pl.cuts, dtype=np.uint64), shard_mix_np(x).astype(np.uint64), side="right").astype(np.int64)
+    if pl is not None and pl.place:
+        keys = np.array(sorted(pl.place), dtype=np.uint32)
+        vals = np.array([pl.place[int(k)] for k in keys], dtype=np.int64)
+        pos = np.searchsorted(keys, x)
+        hit = (pos < keys.size) & (keys[np.minimum(pos, keys.size - 1)] == x)
+        own = np.where(hit, vals[np.minimum(pos, keys.size - 1)], own)
+    return own
 
 
 class NumpyPartitioner:
+    pl = None
+
+    def set_placement(self, pl):
+        self.pl = pl
+
     def partition(self, x, y, v, world):
         xn = x.numpy().view(np.uint32)
-        own = shard_of_np(xn, world)
+        own = owner_np(xn, world, self.pl)
         order = np.argsort(own, kind="stable")
         perm = np.empty_like(order); perm[order] = np.arange(order.size)
         counts = np.bincount(own, minlength=world).tolist()
@@ -57,6 +81,13 @@ class OracleShard:
     def __init__(self):
         self.m = O.Oracle()
 
+    def row_count(self):
+        return self.m.num_rows()
+
+    def displaced_rows(self, rank, world):
+        rows = self.m.list_rows()
+        return rows[shard_of_np(rows, world) != rank].tolist()
+
     def apply(self, op, x, y, v, out):
         r = self.m.apply(op, x.numpy().view(np.uint32), y.numpy().view(np.uint32),
                          v.numpy().view(np.uint32) if v is not None else None)
@@ -76,9 +107,11 @@ def main():
     lib = _lib.load()
     probe = np.array([0, 1, 2, 12345, 0xFFFFFFFF, 0x80000000, 777777], dtype=np.uint32)
     assert [lib.smatrix_shard_of(int(p), world) for p in probe] == shard_of_np(probe, world).tolist()
+    assert [lib.smatrix_shard_mix(int(p)) for p in probe] == shard_mix_np(probe).tolist()
 
     packed = os.environ.get("SMX_TEST_PACKED") == "1"
-    sm = ShardedMatrix(shard=OracleShard(), partitioner=NumpyPackedPartitioner() if packed else NumpyPartitioner())
+    sm = ShardedMatrix(shard=OracleShard(), partitioner=NumpyPackedPartitioner() if packed else NumpyPartitioner(),
+                       auto_place=os.environ.get("SMX_TEST_PLACE", "1") == "1")
     n = 30000 + 1000 * rank                          # ragged batch sizes
     gen = Stream("zipf", 12345 + rank, 50000, 1.1, 1)
     x, y = gen.fill(0, n)
@@ -126,7 +159,17 @@ def main():
     assert lens.tolist() == [ref.rowlen(int(v)) for v in q.numpy().view(np.uint32)]
     # every row lives on exactly its owner, with the same length as in the single matrix
     rows = sm.shard.m.list_rows()
-    assert (shard_of_np(rows, world) == rank).all(), "a row landed on the wrong shard"
+    assert (owner_np(rows, world, sm.placement) == rank).all(), "a row landed on the wrong shard"
+    assert all(sm.owner(int(r)) == rank for r in rows[:300])
+    if sm.auto_place:
+        # the plan moved hot rows and narrowed the loaded shards' ranges: op counts per shard within 15 %
+        # of the mean (equal ranges on this stream: the owner of the hottest row carries ~1.6x)
+        own = owner_np(np.concatenate([allp[r][0, :int(sizes[r])].numpy().view(np.uint32) for r in range(world)]),
+                       world, sm.placement)
+        share = np.bincount(own, minlength=world) / own.size * world
+        assert sm.placement.place and share.max() < 1.15, share
+        if rank == 0:
+            print("placement: %d rows placed, load/mean per shard %s" % (len(sm.placement.place), np.round(share, 3).tolist()))
     assert all(sm.shard.m.rowlen(int(r)) == ref.rowlen(int(r)) for r in rows[:500])
     tot = torch.tensor([rows.size]); dist.all_reduce(tot)
     assert int(tot) == ref.num_rows()

@@ -9,12 +9,41 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("packed,split", [("0", "0"), ("1", "0"), ("1", "1")])
-def test_sharded_two_ranks_gloo(packed, split):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SMX_TEST_PACKED=packed, SMX_TEST_SPLIT=split)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(29533 + int(packed) + 2 * int(split)),
+@pytest.mark.parametrize("packed,split,place,world", [("0", "0", "1", 2), ("1", "0", "1", 2), ("1", "1", "1", 2),
+                                                      ("1", "1", "0", 2), ("1", "0", "1", 4)])
+def test_sharded_ranks_gloo(packed, split, place, world):
+    """place=1: skew-aware placement planned from the first batch (hot rows one by one + unequal hash
+    ranges); place=0: equal hash ranges.  world 4 exercises more than one cut point."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SMX_TEST_PACKED=packed, SMX_TEST_SPLIT=split, SMX_TEST_PLACE=place)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29533 + int(packed) + 2 * int(split) + 4 * int(place) + 8 * world),
            os.path.join(ROOT, "tests", "sharded_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    assert "SHARDED_OK world=2" in p.stdout
+    assert "SHARDED_OK world=%d" % world in p.stdout
+    if place == "1":
+        assert "placement:" in p.stdout
+
+
+def test_plan_placement_balances_zipf():
+    """the planner alone on the analytic Zipf(1.1) row marginal of config 2/4, 8 shards: equal hash ranges
+    leave the hottest row's owner at ~1.9x the mean; the plan is flat"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from libsmatrix_amd.sharded import Placement, plan_placement
+    n_ids, total, world = 1000000, 8 << 24, 8
+    p = np.arange(1, n_ids + 1) ** -1.1
+    p /= p.sum()
+    counts = {i + 1: int(p[i] * total) for i in range(2000)}
+    pl = plan_placement(counts, total, world, 256)
+    assert len(pl.place) == 256 and pl.cuts == sorted(pl.cuts) and len(pl.cuts) == world - 1
+    hot = dict(sorted(counts.items(), key=lambda kv: -kv[1])[:256])
+    load = np.zeros(world)
+    for x, c in hot.items():
+        load[pl.place[x]] += c
+    edges = np.array([0] + pl.cuts + [1 << 32], dtype=np.float64)
+    load += (total - sum(hot.values())) * np.diff(edges) / 2.0 ** 32
+    assert load.max() / (total / world) < 1.01, load / (total / world)
+    assert float(p[0]) * world > 0.99                      # why: the hottest row alone is one shard's fair share
+    back = Placement.from_json(pl.to_json())
+    assert back.cuts == pl.cuts and back.place == pl.place and back.world == world
