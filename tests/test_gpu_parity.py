@@ -421,6 +421,48 @@ def test_big_rows_subcounters(G, oracle_mod, tmp_path):
     m.close(); o2.close(); g.close(); o.close()
 
 
+def test_growth_every_size_one_op_at_a_time(G, oracle_mod):
+    """One op per call (= the scalar ABI's semantics), so every table must be BYTE-identical to the
+    reference's at every size: two rows grow from 16 to 32768 cells through the in-LDS rehash by a wave
+    (<= 256 old cells), by a 256-lane and a 1024-lane workgroup (<= 8192) and the chunked passes beyond;
+    the second row is salted with y = 0 writes and keys congruent to 0 so that the uncounted (0,v) cell
+    appears, vanishes and leaves DUPLICATE keys behind (quirks Q1/Q3), which the resize must merge the
+    reference's way (the sequential redo in k_grow_commit)."""
+    rng = np.random.default_rng(77)
+    g, o = G(), oracle_mod.Oracle()
+    one = lambda a: np.array([a], dtype=np.uint32)
+
+    def both(op, x, y, v):
+        a = g.apply(op, one(x), one(y), one(v))[0]
+        b = o.apply(op, one(x), one(y), one(v))[0]
+        assert a == b, (op, x, y, v, a, b)
+
+    def same_tables(tag):
+        for x in (5, 6):
+            assert g.row_info(x) == o.row_info(x), (tag, x, g.row_info(x), o.row_info(x))
+            assert (np.asarray(g.row_slots(x)) == np.asarray(o.row_slots(x))).all(), (tag, x)
+
+    for step in range(9200):
+        both(2, 5, int(rng.integers(1, 1 << 30)), 1)                      # row 5: plain inserts
+        r = rng.random()
+        size = (o.row_info(6) or (16, 0))[0]
+        if r < 0.55:
+            both(2, 6, int(rng.integers(1, 1 << 30)), 3)
+        elif r < 0.70:
+            both(2, 6, int(rng.integers(1, 64)) * size, 1)                 # home slot 0: piles up behind (0,v)
+        elif r < 0.80:
+            both(2, 6, 0, 7)                                               # y = 0: the uncounted (0,v) cell ...
+        elif r < 0.90:
+            both(3, 6, 0, 7)                                               # ... and back to (0,0) = empty
+        else:
+            both(1, 6, int(rng.integers(1, 64)) * size, int(rng.integers(0, 3)))
+        if step % 700 == 0:
+            same_tables(step)
+    same_tables("end")
+    assert o.row_info(5)[0] >= 16384 and o.row_info(6)[0] >= 8192
+    g.close(); o.close()
+
+
 def test_config1_stock_benchmark_pattern(G, oracle_mod):
     """BASELINE config 1: the reference benchmark's fixed 23x22 id block (src/smatrix_benchmark.c:29-65),
     T threads' ops as one batch each for incr then get -- heavy duplication inside a batch"""
