@@ -12,7 +12,12 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <linux/falloc.h>
+#include <sys/uio.h>
+
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -101,30 +106,37 @@ struct Arena {
     if (bytes <= mapped) return;
     if (vmm) {
       HIP_OK(hipStreamSynchronize(st));   // nothing may be running on the range while its access is re-set
-      size_t add = (bytes - mapped + gran - 1) / gran * gran;
-      if (mapped + add > reserved) smx_die("row arena exhausted (all of HBM reserved)");
+      size_t total = (bytes - mapped + gran - 1) / gran * gran;
+      if (mapped + total > reserved) smx_die("row arena exhausted (all of HBM reserved)");
       hipMemAllocationProp prop = {};
       prop.type = hipMemAllocationTypePinned;
       prop.location.type = hipMemLocationTypeDevice;
       prop.location.id = device;
-      hipMemGenericAllocationHandle_t h;
-      HIP_OK(hipMemCreate(&h, add, &prop, 0));
-      HIP_OK(hipMemMap(base + mapped, add, 0, h, 0));
       hipMemAccessDesc ad = {};
       ad.location.type = hipMemLocationTypeDevice;
       ad.location.id = device;
       ad.flags = hipMemAccessFlagsProtReadWrite;
-      // Access for the new chunk only where the runtime takes a sub-range (the HIP 7.0 runtime bundled
-      // with PyTorch does; there the whole-range form costs ~8 ms per mapped GB: 30-60 ms per growth of a
-      // 5-7 GB arena).  ROCm 7.2's own runtime rejects a sub-range with hipErrorInvalidValue
-      // (tools/probe/vmm.cpp) and does the whole range in microseconds -- so: try, then fall back.
-      if (hipMemSetAccess(base + mapped, add, &ad, 1) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_OK(hipMemSetAccess(base, mapped + add, &ad, 1));
+      // physical chunks (and the fills that zero them) of at most 1 GiB each: a growth step of a 10+ GB
+      // arena is several GiB, and single > 4 GiB allocations / fills are not something to depend on
+      const size_t kChunk = std::max<size_t>(gran, 1ull << 30) / gran * gran;
+      while (total) {
+        const size_t add = std::min(total, kChunk);
+        hipMemGenericAllocationHandle_t h;
+        HIP_OK(hipMemCreate(&h, add, &prop, 0));
+        HIP_OK(hipMemMap(base + mapped, add, 0, h, 0));
+        // Access for the new chunk only where the runtime takes a sub-range (the HIP 7.0 runtime bundled
+        // with PyTorch does; there the whole-range form costs ~8 ms per mapped GB: 30-60 ms per growth of a
+        // 5-7 GB arena).  ROCm 7.2's own runtime rejects a sub-range with hipErrorInvalidValue
+        // (tools/probe/vmm.cpp) and does the whole range in microseconds -- so: try, then fall back.
+        if (hipMemSetAccess(base + mapped, add, &ad, 1) != hipSuccess) {
+          (void)hipGetLastError();
+          HIP_OK(hipMemSetAccess(base, mapped + add, &ad, 1));
+        }
+        HIP_OK(hipMemsetAsync(base + mapped, 0, add, st));
+        chunks.push_back({h, add});
+        mapped += add;
+        total -= add;
       }
-      HIP_OK(hipMemsetAsync(base + mapped, 0, add, st));
-      chunks.push_back({h, add});
-      mapped += add;
     } else {
       size_t nb = std::max(bytes, mapped * 2);
       uint8_t* p = nullptr;
@@ -199,6 +211,7 @@ struct Matrix {
 
   DevBuf<uint32_t> defer[2];
   DevBuf<GrowTask> tasks;
+  unsigned io_threads = 16;             // host threads of the file loader / writer (SMATRIX_IO_THREADS; 1 = the serial code)
   DevBuf<uint32_t> klist;               // growth tasks of kind k at [k * klist_cap, ...), k = 0..2
   uint32_t klist_cap = 0;
   DevBuf<uint32_t> rebal;
@@ -551,6 +564,8 @@ smatrix_t* smatrix_open(const char* fname) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
+  m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
   if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
   const char* prof = getenv("SMATRIX_PROFILE");
   m->profile = prof && *prof == '1';
@@ -574,9 +589,14 @@ void smatrix_close(smatrix_t* self) {
     set_device(m);
     {
       std::lock_guard<std::mutex> g(m->mu);
-      if (!m->fname.empty() && self->fd) file_store(self, m);
+      if (!m->fname.empty() && self->fd) {
+        if (m->io_threads > 1) file_store(self, m);
+        else file_store_serial(self, m);
+      }
       (void)hipStreamSynchronize(m->stream);
+      PhaseClock clk(m->trace_rounds, "close");
       m->arena.destroy();
+      clk.lap("arena unmapped");
       if (m->d_dir) (void)hipFree(m->d_dir);
       if (m->d_ctl) (void)hipFree(m->d_ctl);
       if (m->h_ctl) (void)hipHostFree(m->h_ctl);
@@ -590,8 +610,13 @@ void smatrix_close(smatrix_t* self) {
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
       if (m->stream) (void)hipStreamDestroy(m->stream);
+      clk.lap("buffers freed");
     }
-    if (self->fd) close(self->fd);
+    if (self->fd) {
+      PhaseClock clk(m->trace_rounds, "close");
+      close(self->fd);
+      clk.lap("close(fd)");
+    }
     delete m;
   }
   free(self);
