@@ -58,6 +58,12 @@ inline uint32_t blocks_for(uint64_t n, uint32_t per = 256) {
 }
 
 // ---- row arena: one contiguous VA range, physical memory mapped on demand ------
+// zero-fill in pieces of at most 1 GiB (a single > 4 GiB fill faulted when the arena grew by one, see Arena)
+inline void zero_async(void* p, size_t bytes, hipStream_t st) {
+  for (size_t off = 0; off < bytes; off += (size_t)1 << 30)
+    HIP_OK(hipMemsetAsync(static_cast<uint8_t*>(p) + off, 0, std::min<size_t>((size_t)1 << 30, bytes - off), st));
+}
+
 struct Arena {
   uint8_t* base = nullptr;
   size_t mapped = 0;       // bytes usable
@@ -141,7 +147,7 @@ struct Arena {
       size_t nb = std::max(bytes, mapped * 2);
       uint8_t* p = nullptr;
       HIP_OK(hipMalloc(&p, nb));
-      HIP_OK(hipMemsetAsync(p, 0, nb, st));
+      zero_async(p, nb, st);
       if (base && live) HIP_OK(hipMemcpyAsync(p, base, live, hipMemcpyDeviceToDevice, st));
       HIP_OK(hipStreamSynchronize(st));
       if (base) HIP_OK(hipFree(base));
@@ -211,6 +217,7 @@ struct Matrix {
 
   DevBuf<uint32_t> defer[2];
   DevBuf<GrowTask> tasks;
+  uint64_t io_window = 256ull << 20;    // bytes per window of the file loader / writer
   unsigned io_threads = 16;             // host threads of the file loader / writer (SMATRIX_IO_THREADS; 1 = the serial code)
   DevBuf<uint32_t> klist;               // growth tasks of kind k at [k * klist_cap, ...), k = 0..2
   uint32_t klist_cap = 0;
@@ -304,7 +311,7 @@ void grow_directory(Matrix* m, uint32_t factor, hipStream_t s) {
   uint32_t ns = (uint32_t)ns64;
   DirSlot* nd = nullptr;
   HIP_OK(hipMalloc(&nd, (size_t)ns * sizeof(DirSlot)));
-  HIP_OK(hipMemsetAsync(nd, 0, (size_t)ns * sizeof(DirSlot), s));
+  zero_async(nd, (size_t)ns * sizeof(DirSlot), s);
   hipLaunchKernelGGL(k_dir_rehash, dim3(blocks_for(m->dir_size)), dim3(256), 0, s, m->d_dir,
                      m->dir_size, nd, ns - 1);
   HIP_OK(hipGetLastError());
@@ -556,7 +563,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipEventCreate(&m->ev1));
   m->dir_size = 65536;                               // SMATRIX_CMAP_INITIAL_SIZE, src/smatrix.h:24
   HIP_OK(hipMalloc(&m->d_dir, (size_t)m->dir_size * sizeof(DirSlot)));
-  HIP_OK(hipMemsetAsync(m->d_dir, 0, (size_t)m->dir_size * sizeof(DirSlot), m->stream));
+  zero_async(m->d_dir, (size_t)m->dir_size * sizeof(DirSlot), m->stream);
   m->arena.init(dev, 4u << 20, m->stream);
   HIP_OK(hipStreamSynchronize(m->stream));
   ctl_push_persistent(m, m->stream);
@@ -565,6 +572,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
   m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
   if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
   const char* prof = getenv("SMATRIX_PROFILE");

@@ -330,6 +330,75 @@ def test_file_roundtrip_and_cross_open(G, oracle_mod, tmp_path, golden):
         w.close()
 
 
+def test_file_loader_windows_and_foreign_files(G, oracle_mod, tmp_path, monkeypatch):
+    """the windowed multi-thread loader/writer on a file that (a) spans many windows (1 MB windows here),
+    (b) holds a row block larger than a window, (c) lists a row id TWICE (the later entry wins,
+    src/smatrix.c:823), (d) holds a row block whose size is not 16*2^k (legal for the reference's reader,
+    which probes `key % size`); same answers as the oracle reading the same bytes, and as the one-thread
+    code path"""
+    import struct
+    rng = np.random.default_rng(31)
+    path = str(tmp_path / "foreign.smx")
+    o = oracle_mod.Oracle(path)
+    x = rng.integers(1, 3000, 150000, dtype=np.uint32); y = rng.integers(1, 1 << 20, 150000, dtype=np.uint32)
+    o.apply(2, x, y, np.ones(x.size, np.uint32))
+    by = rng.permutation(np.arange(1, 200000, dtype=np.uint32))[:40000]            # row 7777: 2^17 cells = 1 MB
+    o.apply(2, np.full(by.size, 7777, np.uint32), by, np.full(by.size, 3, np.uint32))
+    o.close()
+    with open(path, "r+b") as f:
+        raw = f.read()
+        assert raw[:8] == b"\x17" * 8
+        cmap_at = struct.unpack_from("<Q", raw, 8)[0]
+        n_ent, nxt = struct.unpack_from("<QQ", raw, cmap_at)
+        assert nxt == 0
+        k = 0
+        while struct.unpack_from("<Q", raw, cmap_at + 16 + 12 * k + 4)[0]:
+            k += 1
+        first_x = struct.unpack_from("<I", raw, cmap_at + 16)[0]
+        end = len(raw)
+        # (c) a second entry for the first row id, pointing at a fresh 16-slot block {(5,50),(21,210)}
+        blk_c = bytearray(b"\x23" * 8 + struct.pack("<Q", 16) + bytes(16 * 8))
+        struct.pack_into("<II", blk_c, 16 + 8 * 5, 5, 50)
+        struct.pack_into("<II", blk_c, 16 + 8 * 6, 21, 210)                         # 21 % 16 = 5 -> probes to slot 6
+        # (d) a new row 999999 in a 24-slot block: keys at `key % 24`, one collision chain
+        blk_d = bytearray(b"\x23" * 8 + struct.pack("<Q", 24) + bytes(24 * 8))
+        for key, val in ((3, 30), (27, 270), (51, 510), (23, 230)):
+            q = key % 24
+            while struct.unpack_from("<I", blk_d, 16 + 8 * q)[0]:
+                q = (q + 1) % 24
+            struct.pack_into("<II", blk_d, 16 + 8 * q, key, val)
+        f.seek(end); f.write(blk_c); f.write(blk_d)
+        f.seek(cmap_at + 16 + 12 * k)
+        f.write(struct.pack("<IQ", first_x, end) + struct.pack("<IQ", 999999, end + len(blk_c)))
+    ref = oracle_mod.Oracle(path)
+    qx = np.concatenate([x, np.full(by.size, 7777, np.uint32), np.full(4, first_x, np.uint32), np.full(5, 999999, np.uint32)])
+    qy = np.concatenate([y, by, np.array([5, 21, 6, 37], np.uint32), np.array([3, 27, 51, 23, 4], np.uint32)])
+    want = ref.apply(0, qx, qy)
+    rows = np.unique(qx)
+    lens = [ref.rowlen(int(r)) for r in rows]
+    ref.close()
+    assert want[-9:].tolist() == [50, 210, 0, 0, 30, 270, 510, 230, 0]               # the later entry replaced the row
+    got = {}
+    for name, env in (("windows", {"SMATRIX_IO_WINDOW_MB": "1", "SMATRIX_IO_THREADS": "4"}), ("default", {}),
+                      ("serial", {"SMATRIX_IO_THREADS": "1"})):
+        for k_, v_ in (("SMATRIX_IO_WINDOW_MB", None), ("SMATRIX_IO_THREADS", None)):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        import shutil
+        p2 = str(tmp_path / ("copy_%s.smx" % name))
+        shutil.copy(path, p2)
+        m = G(p2)
+        assert (m.apply(0, qx, qy) == want).all(), name
+        assert m.m.rowlen_batch(rows).tolist() == lens, name
+        m.apply(2, qx[:1000], qy[:1000] + (1 << 21), np.ones(1000, np.uint32))      # grow a little, write it back
+        m.close()
+        back = oracle_mod.Oracle(p2)                                                # our rewrite, read by the oracle
+        assert (back.apply(0, qx, qy) == want).all(), name
+        assert (back.apply(0, qx[:1000], qy[:1000] + (1 << 21)) >= 1).all(), name
+        back.close()
+
+
 def test_sharded_path_one_rank_nccl():
     """the HIP partitioner + RCCL all_to_all + local shard with world_size 1 (all a 1-GPU box allows):
     bench.py --force-sharded must produce the same sane line as the direct path"""
