@@ -1260,33 +1260,74 @@ __global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, ui
   uint32_t lane = threadIdx.x & 63;
   uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint64_t lt = (1ull << lane) - 1;
-  for (uint32_t r = wave; r < n; r += nwaves) {
-    uint4 s;
-    DirSlot* d = dir_find(dir, dmask, xs[r], &s);
-    uint32_t written = 0;
-    if (d && s.z != 0) {
-      const uint32_t size = 1u << meta_lg(s.x);
-      if (size > GETROW_WAVE_MAX) {
-        if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = r;
+  // A row is a chain of dependent accesses (id -> directory slot -> cells -> pairs out) and a CF-shaped
+  // row is only 1-2 KiB: a wave that walks one row at a time spends its life waiting.  Two rows are in
+  // flight per wave instead: both directory slots are requested together, then both rows' first 128 cells.
+  struct Row {
+    bool live, scan;
+    uint32_t r, size, cap, written;
+    uint64_t off;
+    const uint4* cells;
+    uint4 c;
+  };
+  auto step = [&](Row& w, uint32_t p0) {             // compacts the 128 cells held in w.c (slot order)
+    const bool ne0 = (w.c.x | w.c.y) != 0, ne1 = (w.c.z | w.c.w) != 0;
+    const uint64_t m0 = __ballot(ne0), m1 = __ballot(ne1);
+    uint32_t rank = w.written + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt);
+    if (ne0 && rank < w.cap) ret[w.off + rank] = pack_cell(w.c.x, w.c.y);
+    rank += ne0;
+    if (ne1 && rank < w.cap) ret[w.off + rank] = pack_cell(w.c.z, w.c.w);
+    w.written += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+    (void)p0;
+  };
+  auto fetch = [&](const Row& w, uint32_t p0) -> uint4 {
+    const uint32_t p = p0 + 2 * lane;
+    return p < w.size ? w.cells[p >> 1] : make_uint4(0, 0, 0, 0);
+  };
+  for (uint32_t r0 = wave; r0 < n; r0 += 2 * nwaves) {
+    Row w[2];
+    uint32_t X[2], h[2];
+    uint4 s[2];
+    for (int k = 0; k < 2; k++) {
+      w[k].r = r0 + k * nwaves;
+      w[k].live = w[k].r < n;
+      w[k].scan = false;
+      w[k].written = 0;
+      X[k] = w[k].live ? xs[w[k].r] : 0u;
+      h[k] = fmix32(X[k]) & dmask;
+    }
+    for (int k = 0; k < 2; k++) s[k] = *reinterpret_cast<const uint4*>(&dir[h[k]]);     // both in flight
+    for (int k = 0; k < 2; k++) {
+      if (!w[k].live) continue;
+      while ((s[k].x & META_USED) && s[k].y != X[k]) {                                   // rare: probe on
+        h[k] = (h[k] + 1) & dmask;
+        s[k] = *reinterpret_cast<const uint4*>(&dir[h[k]]);
+      }
+      if (!(s[k].x & META_USED) || s[k].z == 0) continue;                                // no such row: 0 pairs
+      w[k].size = 1u << meta_lg(s[k].x);
+      if (w[k].size > GETROW_WAVE_MAX) {
+        if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = w[k].r;
+        w[k].live = false;                                                               // k_getrow_big writes its count
         continue;
       }
-      const uint64_t off = offsets[r];
-      const uint32_t cap = getrow_cap(offsets, r);
-      const uint4* cells = reinterpret_cast<const uint4*>(row_cells(arena, s.z));
-      for (uint32_t p0 = 0; p0 < size && written < cap; p0 += 128) {
-        const uint32_t p = p0 + 2 * lane;
-        uint4 c = p < size ? cells[p >> 1] : make_uint4(0, 0, 0, 0);
-        const bool ne0 = (c.x | c.y) != 0, ne1 = (c.z | c.w) != 0;
-        const uint64_t m0 = __ballot(ne0), m1 = __ballot(ne1);
-        uint32_t rank = written + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt);
-        if (ne0 && rank < cap) ret[off + rank] = pack_cell(c.x, c.y);
-        rank += ne0;
-        if (ne1 && rank < cap) ret[off + rank] = pack_cell(c.z, c.w);
-        written += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
-      }
-      if (written > cap) written = cap;
+      w[k].off = offsets[w[k].r];
+      w[k].cap = getrow_cap(offsets, w[k].r);
+      w[k].cells = reinterpret_cast<const uint4*>(row_cells(arena, s[k].z));
+      w[k].scan = true;
     }
-    if (lane == 0) counts[r] = written;
+    for (int k = 0; k < 2; k++)
+      if (w[k].scan) w[k].c = fetch(w[k], 0);                                            // both in flight
+    for (int k = 0; k < 2; k++) {
+      if (w[k].scan) {
+        step(w[k], 0);
+        for (uint32_t p0 = 128; p0 < w[k].size && w[k].written < w[k].cap; p0 += 128) {
+          w[k].c = fetch(w[k], p0);
+          step(w[k], p0);
+        }
+        if (w[k].written > w[k].cap) w[k].written = w[k].cap;
+      }
+      if (w[k].live && lane == 0) counts[w[k].r] = w[k].written;
+    }
   }
 }
 
