@@ -66,12 +66,36 @@ def cpu_baseline(sample_ops, torch, dev):
         t_get += t2 - t1
     rows = m.num_rows()
     m.close()
-    return {
+    res = {
         "value": round(2 * sample_ops / (t_incr + t_get) / 1e6, 3), "unit": "Mops/s", "cores": 1, "kind": kind,
         "sample": "first %d ops of the same Zipf stream in batches of 2^24 (incr batch then get batch): "
                   "incr %.2fs + get %.2fs, 1 thread, %d rows at the end; host has %d cores"
                   % (sample_ops, t_incr, t_get, rows, os.cpu_count()),
     }
+    if kind == "reference":
+        # the reference is thread-safe (per-row spin RW locks, src/smatrix.c:843-889): the same ops split in
+        # contiguous slices over 8 threads, thread start inside the timed region as in smatrix_benchmark.c:109-122
+        import threading
+        T, n8 = 8, min(sample_ops, 1 << 25)
+        m = O.Reference()
+        t8 = 0.0
+        for a in range(0, n8, chunk):
+            xs, ys = x[a:a + chunk], y[a:a + chunk]
+            ones = np.ones(xs.size, np.uint32)
+            per = (xs.size + T - 1) // T
+            for op in (O.OP_INCR, O.OP_GET):
+                th = [threading.Thread(target=m.apply, args=(op, xs[i * per:(i + 1) * per], ys[i * per:(i + 1) * per],
+                                                             ones[i * per:(i + 1) * per])) for i in range(T)]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                t8 += time.perf_counter() - t0
+        m.close()
+        res["threads_8"] = {"value": round(2 * n8 / t8 / 1e6, 3), "unit": "Mops/s", "cores": T,
+                            "sample": "first %d ops, each batch split over 8 threads: %.2fs" % (n8, t8)}
+    return res
 
 
 def random_access_roofline(torch, dev, gib=4, touches=1 << 27):
