@@ -20,6 +20,15 @@ def t(label, fn, reps=5):
     torch.cuda.synchronize()
     print("%-40s %8.3f ms" % (label, (time.perf_counter() - t0) / reps * 1e3)); return r
 counts, perm, xo, yo, vo = t("partition (3 arrays)", lambda: part.partition(x, y, v, 1))
+# the same with 8 shards and a planned placement (256 hot rows + unequal ranges)
+from libsmatrix_amd.sharded import plan_placement
+ux, cnt = torch.unique(x, return_counts=True); top = torch.topk(cnt, 256).indices
+pl = plan_placement({int(a) & 0xFFFFFFFF: int(c) for a, c in zip(ux[top].tolist(), cnt[top].tolist())}, B, 8, 256)
+c8 = t("partition packed, 8 shards, equal ranges", lambda: part.partition_packed(x, y, v, 8))[0]
+part.set_placement(pl)
+c8p = t("partition packed, 8 shards, planned", lambda: part.partition_packed(x, y, v, 8))[0]
+part.set_placement(None)
+print("ops per shard / mean: equal ranges %s  planned %s" % ([round(c * 8 / B, 2) for c in c8], [round(c * 8 / B, 2) for c in c8p]))
 counts, perm, po = t("partition packed [n,3]", lambda: part.partition_packed(x, y, v, 1))
 pr = torch.empty_like(po); xr = torch.empty_like(xo)
 t("all_to_all_single packed [n,3]", lambda: dist.all_to_all_single(pr, po, counts, counts))
