@@ -78,8 +78,8 @@ class NumpyPackedPartitioner(NumpyPartitioner):
 
 
 class OracleShard:
-    def __init__(self):
-        self.m = O.Oracle()
+    def __init__(self, fname=None):
+        self.m = O.Oracle(fname)
 
     def row_count(self):
         return self.m.num_rows()
@@ -174,8 +174,30 @@ def main():
     tot = torch.tensor([rows.size]); dist.all_reduce(tot)
     assert int(tot) == ref.num_rows()
     sm.close(); ref.close()
+    # file-backed shards: the plan is stored next to them and taken over at reopen (reads first, then writes)
+    import tempfile
+    d = [tempfile.mkdtemp(prefix="smxgloo_") if rank == 0 else None]
+    dist.broadcast_object_list(d, src=0)
+    fname = os.path.join(d[0], "shard%d.smx" % rank)
+    mk = lambda: ShardedMatrix(shard=OracleShard(fname), partitioner=NumpyPackedPartitioner(), placement_file=fname + ".placement",
+                               auto_place=os.environ.get("SMX_TEST_PLACE", "1") == "1")
+    fm = mk()
+    fm.apply_dev(2, xt, yt, ones, out_i)
+    fm.apply_dev(0, xt, yt, None, out_g)
+    want_g, plan = out_g.clone(), fm.placement.to_json()
+    fm.close()
+    fm = mk()
+    got = torch.empty_like(out_g)
+    fm.apply_dev(0, xt, yt, None, got)                       # a READ is the first call after the reopen
+    assert fm.placement.to_json() == plan and torch.equal(got, want_g)
+    fm.apply_dev(2, xt, yt, ones, out_i)
+    fm.apply_dev(0, xt, yt, None, got)
+    assert torch.equal(got, want_g * 2)
+    fm.close()
     dist.barrier()
     if rank == 0:
+        import shutil
+        shutil.rmtree(d[0], ignore_errors=True)
         print("SHARDED_OK world=%d rows=%d" % (world, int(tot)))
     dist.destroy_process_group()
 
