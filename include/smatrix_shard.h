@@ -41,7 +41,7 @@ size_t smatrix_displaced_rows(smatrix_t* self, uint32_t rank, uint32_t nshards, 
 
 /* Reorders the n ops shard by shard.  counts_host[s] (host) = ops owned by shard s;
  * d_perm[i] = position of op i in the reordered arrays d_xo/d_yo/d_vo (d_v, d_vo may be NULL);
- * d_work: >= 512 bytes of device scratch.  Synchronises hip_stream.  Returns 0 on success. */
+ * d_work: >= 1024 bytes of device scratch.  Synchronises hip_stream (once).  Returns 0 on success. */
 int smatrix_partition_dev(size_t n, const uint32_t* d_x, const uint32_t* d_y, const uint32_t* d_v,
                           uint32_t nshards, uint64_t* counts_host, void* d_work, uint32_t* d_perm,
                           uint32_t* d_xo, uint32_t* d_yo, uint32_t* d_vo, const uint32_t* d_place,

@@ -1498,6 +1498,16 @@ __global__ __launch_bounds__(256) void k_part_count(uint32_t n, const uint32_t* 
   if (threadIdx.x < nshards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+// between the passes: counts -> exclusive offsets (the scatter's cursors), on the device so that the host
+// waits once per partition instead of twice.  work[0..63] = counts (kept for the host), work[64..127] = cursors
+__global__ void k_part_offsets(unsigned long long* work, uint32_t nshards) {
+  unsigned long long run = 0;
+  for (uint32_t i = 0; i < nshards; i++) {
+    work[MAX_SHARDS + i] = run;
+    run += work[i];
+  }
+}
+
 // pass 2: scatter into shard-contiguous order.  cursors[] start at the exclusive offsets; a
 // workgroup reserves its range per shard with one global atomic, lanes rank inside it in LDS.
 // perm[i] = position of op i in the partitioned arrays (used to route results back).

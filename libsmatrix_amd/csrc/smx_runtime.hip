@@ -990,24 +990,18 @@ static int partition_impl(size_t n, const uint32_t* d_x, const uint32_t* d_y, co
   if (place_slots > PLACE_MAX_SLOTS || (place_slots & (place_slots - 1)) || (place_slots && !d_place)) return -1;
   const uint2* place = reinterpret_cast<const uint2*>(d_place);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  unsigned long long* work = static_cast<unsigned long long*>(d_work);   // >= 64 * 8 bytes
-  HIP_OK(hipMemsetAsync(work, 0, MAX_SHARDS * sizeof(unsigned long long), s));
+  unsigned long long* work = static_cast<unsigned long long*>(d_work);   // 2 x 64 x 8 bytes: counts, cursors
+  HIP_OK(hipMemsetAsync(work, 0, 2 * MAX_SHARDS * sizeof(unsigned long long), s));
   if (n) {
     hipLaunchKernelGGL(k_part_count, dim3(std::min<uint32_t>(blocks_for(n), 2048)), dim3(256), 0, s,
                        (uint32_t)n, d_x, nshards, work, place, place_slots, d_cuts);
+    hipLaunchKernelGGL(k_part_offsets, dim3(1), dim3(1), 0, s, work, nshards);
+    hipLaunchKernelGGL(k_part_scatter, dim3(blocks_for(n, 256 * PART_OPT)), dim3(256), 0, s, (uint32_t)n,
+                       d_x, d_y, d_v, nshards, work + MAX_SHARDS, d_perm, d_xo, d_yo, d_vo, d_packed, place, place_slots, d_cuts);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipMemcpyAsync(counts_host, work, nshards * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
-  unsigned long long cur[MAX_SHARDS] = {0}, run = 0;
-  for (uint32_t i = 0; i < nshards; i++) { cur[i] = run; run += counts_host[i]; }
-  HIP_OK(hipMemcpyAsync(work, cur, nshards * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-  if (n) {
-    hipLaunchKernelGGL(k_part_scatter, dim3(blocks_for(n, 256 * PART_OPT)), dim3(256), 0, s, (uint32_t)n,
-                       d_x, d_y, d_v, nshards, work, d_perm, d_xo, d_yo, d_vo, d_packed, place, place_slots, d_cuts);
-    HIP_OK(hipGetLastError());
-  }
-  HIP_OK(hipStreamSynchronize(s));   // `cur` lives on this stack frame
   return 0;
 }
 

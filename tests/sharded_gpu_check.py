@@ -28,9 +28,10 @@ for s in range(S):
     h_i = pending.pop(s, None) or sm.route(OP_INCR, xs[s], ys[s], ones)
     h_g = sm.route(OP_GET, xs[s], ys[s])
     sm.apply_routed(h_i); sm.finish(h_i, oi)
+    sm.apply_routed(h_g)
     if s + 1 < S:
         pending[s + 1] = sm.route(OP_INCR, xs[s + 1], ys[s + 1], ones)
-    sm.apply_routed(h_g); sm.finish(h_g, og)
+    sm.finish(h_g, og)
     sm.wait(h_i); sm.wait(h_g)
     torch.cuda.synchronize()
     assert torch.equal(og, dg), "get mismatch at step %d" % s
