@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--cpu-sample-lg", type=int, default=26)
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events (A/B of the overhead)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded path: one blocking apply_dev per op batch")
+    ap.add_argument("--no-comm-thread", action="store_true", help="sharded path: issue the exchange from the main thread")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for test rigs)")
     ap.add_argument("--single-device", action="store_true",
                     help="test rig: every rank uses cuda:0 and the exchange is staged through the host (gloo)")
@@ -196,7 +197,32 @@ def main():
 
     pending = {}       # sharded: batches whose incr records are already travelling (routed ahead)
 
+    # Sharded + overlap: everything that talks to the other ranks (partition, the collectives, gather) runs on
+    # ONE helper thread, in a fixed order, so that the host-side waits of the exchange (split sizes must reach
+    # the host before a collective can be issued) run under the host-driven rounds of the op kernels instead of
+    # in front of them.  The library calls release the GIL; the op kernels stay on the main thread.
+    comm = None
+    if sharded and not args.no_overlap and not args.no_comm_thread:
+        from concurrent.futures import ThreadPoolExecutor
+        comm = ThreadPoolExecutor(max_workers=1, initializer=lambda: torch.cuda.set_device(local))
+
+    def step_threaded(s):
+        f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones)
+        f_g = comm.submit(m.route, OP_GET, xs[s], ys[s])           # travels under the incr kernels of s
+        h_i = f_i.result()
+        m.apply_routed(h_i)
+        f_fi = comm.submit(m.finish, h_i, out_i)
+        h_g = f_g.result()
+        m.apply_routed(h_g)
+        if s + 1 < total_steps and s + 1 != args.warmup:           # never across the timing fence
+            pending[s + 1] = comm.submit(m.route, OP_INCR, xs[s + 1], ys[s + 1], ones)
+        f_fg = comm.submit(m.finish, h_g, out_g)
+        f_fi.result(); f_fg.result()
+        m.wait(h_i); m.wait(h_g)
+
     def step(s):
+        if comm is not None:
+            return step_threaded(s)
         if sharded and not args.no_overlap:
             # exchange of get(s) overlaps the incr kernels of s; exchange of incr(s+1) overlaps get(s)
             h_i = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones)
@@ -324,6 +350,8 @@ def main():
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_sample_lg, torch, dev)
         print(json.dumps(res))
+    if comm is not None:
+        comm.shutdown()
     m.close()
     if sharded:
         dist.destroy_process_group()

@@ -56,6 +56,11 @@ int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uin
 int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d_x,
                             const uint32_t* d_y, const uint32_t* d_v, uint32_t* d_out,
                             void* hip_stream);
+
+/* The same on ONE device array of n records {x, y} (width 2, get only) or {x, y, v} (width 3): the form
+ * in which the sharded exchange delivers a batch (include/smatrix_shard.h) -- no unpacking pass. */
+int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* d_records, uint32_t width,
+                             uint32_t* d_out, void* hip_stream);
 int smatrix_rowlen_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x, uint32_t* d_out,
                              void* hip_stream);
 int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,

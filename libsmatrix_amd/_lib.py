@@ -59,6 +59,7 @@ def load():
         "smatrix_rowlen_batch": (C.c_int, [H, C.c_size_t, u32p, u32p]),
         "smatrix_getrow_batch": (C.c_int, [H, C.c_size_t, u32p, u64p, u32p, u32p]),
         "smatrix_apply_batch_dev": (C.c_int, [H, C.c_int, C.c_size_t, V, V, V, V, V]),
+        "smatrix_apply_packed_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, C.c_uint32, V, V]),
         "smatrix_rowlen_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V]),
         "smatrix_getrow_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V, V, V]),
         "smatrix_cf_neighbors_batch": (C.c_int, [H, C.c_size_t, u32p, u64p, u32p, C.POINTER(C.c_double), u32p]),

@@ -315,7 +315,9 @@ template <int OP>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
-    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
+  // st: distance between consecutive ops in xs/ys/vs, in words (1 = three arrays, 2 / 3 = one array of
+  // {x,y} / {x,y,v} records with xs = rec, ys = rec + 1, vs = rec + 2: what the sharded exchange delivers)
   for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
@@ -323,7 +325,8 @@ __device__ __forceinline__ void apply_body(
     bool deferred = false;
     if (live) {
       j = idx ? idx[t] : t;
-      uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[j], ys[j], OP != OP_GET ? vs[j] : 0u, &deferred);
+      const size_t at = (size_t)j * st;
+      uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[at], ys[at], OP != OP_GET ? vs[at] : 0u, &deferred);
       if (!deferred) out[j] = r;
     }
     if (OP != OP_GET) {
@@ -350,8 +353,8 @@ template <int OP>
 __global__ __launch_bounds__(256) void k_apply(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
-    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
-  apply_body<OP>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer);
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
+  apply_body<OP>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 // ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
@@ -395,7 +398,7 @@ constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/
 #ifndef SMX_AGG_SGPRS
 #define SMX_AGG_SGPRS 80
 #endif
-template <int OP>
+template <int OP, uint32_t ST = 1>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare)
 __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_apply_agg(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -419,8 +422,8 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
     slot[k] = ~0u;                 // ~0: no op; ~0-1: per-op path
     if (t >= n) continue;
     j[k] = idx ? idx[t] : t;
-    const uint32_t X = xs[j[k]], Y = ys[j[k]];
-    V[k] = vs[j[k]];
+    const uint32_t X = xs[(size_t)j[k] * ST], Y = ys[(size_t)j[k] * ST];
+    V[k] = vs[(size_t)j[k] * ST];
     const uint64_t key = (uint64_t)X | ((uint64_t)Y << 32);
     if (Y == 0 || key == ~0ull) { slot[k] = ~0u - 1; continue; }
     uint32_t h = (X * 0x9E3779B1u) ^ (Y * 0x85EBCA77u);
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
   for (uint32_t k = 0; k < AGG_OPT; k++) {
     bool deferred = false;
     if (slot[k] == ~0u - 1) {
-      uint32_t r = apply_one<OP>(dir, dmask, arena, xs[j[k]], ys[j[k]], V[k], &deferred);
+      uint32_t r = apply_one<OP>(dir, dmask, arena, xs[(size_t)j[k] * ST], ys[(size_t)j[k] * ST], V[k], &deferred);
       if (!deferred) out[j[k]] = r;
     } else if (slot[k] != ~0u) {
       deferred = reinterpret_cast<uint32_t*>(&l_key[slot[k]])[0] != 0;
@@ -563,7 +566,7 @@ __device__ __forceinline__ void prep_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl) {
+    FreeLists fl, uint32_t st) {
   // block-scope scratch of the row-creation step
   __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
   __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
@@ -578,8 +581,8 @@ __device__ __forceinline__ void prep_body(
     uint32_t X = 0, Y = 0;
     if (live) {
       const uint32_t j = defer[t];
-      X = xs[j];
-      Y = ys[j];
+      X = xs[(size_t)j * st];
+      Y = ys[(size_t)j * st];
     }
     // A. where does X live?  (read-only probe)
     uint32_t h = fmix32(X) & dmask;
@@ -770,8 +773,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl) {
-  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl);
+    FreeLists fl, uint32_t st) {
+  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st);
 }
 
 // ---- growth -------------------------------------------------------------------
@@ -1162,13 +1165,13 @@ __global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uin
 // applied in place (quirk Q1 path) and take no part.
 __global__ __launch_bounds__(256) void k_set_locate(DirSlot* dir, uint32_t dmask, uint8_t* arena,
                                                     uint32_t n, const uint32_t* __restrict__ xs,
-                                                    const uint32_t* __restrict__ ys, uint64_t* cellp) {
+                                                    const uint32_t* __restrict__ ys, uint64_t* cellp, uint32_t st) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   uint64_t where = ~0ull;
-  const uint32_t Y = ys[j];
+  const uint32_t Y = ys[(size_t)j * st];
   uint4 s;
-  DirSlot* d = Y ? dir_find(dir, dmask, xs[j], &s) : nullptr;
+  DirSlot* d = Y ? dir_find(dir, dmask, xs[(size_t)j * st], &s) : nullptr;
   if (d && s.z) {
     const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
     const uint64_t* cells = row_cells(arena, s.z);
@@ -1198,10 +1201,10 @@ __global__ __launch_bounds__(256) void k_set_pick(uint32_t n, uint64_t* cellp, u
     if (reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] != j + 1) cellp[j] = ~0ull;  // loser
 }
 __global__ __launch_bounds__(256) void k_set_store(uint32_t n, const uint64_t* cellp,
-                                                   const uint32_t* vs, uint8_t* arena) {
+                                                   const uint32_t* vs, uint8_t* arena, uint32_t st) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n && cellp[j] != ~0ull)
-    reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = vs[j];
+    reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = vs[(size_t)j * st];
 }
 
 // ---- directory growth -----------------------------------------------------------

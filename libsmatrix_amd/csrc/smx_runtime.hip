@@ -218,6 +218,7 @@ struct Matrix {
   DevBuf<uint32_t> defer[2];
   DevBuf<GrowTask> tasks;
   uint64_t io_window = 256ull << 20;    // bytes per window of the file loader / writer
+  uint32_t in_stride = 1;               // words between consecutive ops of the batch being applied (3 / 2: packed records)
   unsigned io_threads = 16;             // host threads of the file loader / writer (SMATRIX_IO_THREADS; 1 = the serial code)
   DevBuf<uint32_t> klist;               // growth tasks of kind k at [k * klist_cap, ...), k = 0..2
   uint32_t klist_cap = 0;
@@ -326,15 +327,19 @@ template <int OP>
 void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                   const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
   hipLaunchKernelGGL((k_apply<OP>), dim3(blocks_for(n)), dim3(256), 0, s, m->d_ctl, m->d_dir,
-                     m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+                     m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
   HIP_OK(hipGetLastError());
 }
 
 template <int OP>
 void launch_apply_agg(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                       const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
-  hipLaunchKernelGGL((k_apply_agg<OP>), dim3(blocks_for(n, AGG_TILE)), dim3(AGG_THREADS), 0, s, m->d_ctl,
-                     m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  if (m->in_stride == 3)
+    hipLaunchKernelGGL((k_apply_agg<OP, 3>), dim3(blocks_for(n, AGG_TILE)), dim3(AGG_THREADS), 0, s, m->d_ctl,
+                       m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  else
+    hipLaunchKernelGGL((k_apply_agg<OP>), dim3(blocks_for(n, AGG_TILE)), dim3(AGG_THREADS), 0, s, m->d_ctl,
+                       m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   HIP_OK(hipGetLastError());
 }
 
@@ -448,7 +453,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), 2048)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                        (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
-                       m->rebal.p, m->fl);
+                       m->rebal.p, m->fl, m->in_stride);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
@@ -484,11 +489,11 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   if (op == OP_SET) {
     dim3 g(blocks_for(n)), b(256);
     hipLaunchKernelGGL(k_set_locate, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y,
-                       m->cellp.p);
+                       m->cellp.p, m->in_stride);
     hipLaunchKernelGGL(k_set_clear, g, b, 0, s, n, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_rank, g, b, 0, s, n, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_pick, g, b, 0, s, n, m->cellp.p, m->arena.base);
-    hipLaunchKernelGGL(k_set_store, g, b, 0, s, n, m->cellp.p, v, m->arena.base);
+    hipLaunchKernelGGL(k_set_store, g, b, 0, s, n, m->cellp.p, v, m->arena.base, m->in_stride);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(s));
   }
@@ -638,6 +643,21 @@ int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d
   std::lock_guard<std::mutex> g(m->mu);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   apply_dev_locked(self, op, n, d_x, d_y, d_v, d_out, s);
+  if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* d_records, uint32_t width,
+                             uint32_t* d_out, void* hip_stream) {
+  if (width != 2 && width != 3) return -1;
+  if (op != OP_GET && width != 3) return -1;               // writes need a value
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
+  m->in_stride = width;
+  apply_dev_locked(self, op, n, d_records, d_records + 1, d_records + 2, d_out, s);
+  m->in_stride = 1;
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
 }

@@ -143,6 +143,11 @@ class SparseMatrix:
     def apply_batch_dev(self, op, n, x_ptr, y_ptr, v_ptr, out_ptr, stream=None):
         self._lib.smatrix_apply_batch_dev(self._h, op, n, x_ptr, y_ptr, v_ptr, out_ptr, stream)
 
+    def apply_packed_dev(self, op, n, rec_ptr, width, out_ptr, stream=None):
+        """n records {x,y} (width 2, get) or {x,y,v} (width 3) in ONE device array"""
+        if self._lib.smatrix_apply_packed_dev(self._h, op, n, rec_ptr, width, out_ptr, stream):
+            raise ValueError("smatrix_apply_packed_dev: bad width / op")
+
     def rowlen_batch_dev(self, n, x_ptr, out_ptr, stream=None):
         self._lib.smatrix_rowlen_batch_dev(self._h, n, x_ptr, out_ptr, stream)
 

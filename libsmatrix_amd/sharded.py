@@ -117,6 +117,11 @@ class HipShard:
             self.m.apply_batch_dev(op, n, x.data_ptr(), y.data_ptr(), v.data_ptr() if v is not None else None,
                                    out.data_ptr(), _stream())
 
+    def apply_packed(self, op, rec, out):
+        """rec: [n, 2] ({x,y}, get) or [n, 3] ({x,y,v}) int32 records, as the exchange delivers them"""
+        if rec.shape[0]:
+            self.m.apply_packed_dev(op, rec.shape[0], rec.data_ptr(), rec.shape[1], out.data_ptr(), _stream())
+
     def rowlen(self, x, out):
         if x.numel():
             self.m.rowlen_batch_dev(x.numel(), x.data_ptr(), out.data_ptr(), _stream())
@@ -332,7 +337,8 @@ class ShardedMatrix:
             # one collective for the whole op record (splits count rows of the [n, w] tensor)
             pr = torch.empty((nr, po.shape[1]), dtype=x.dtype, device=x.device)
             self._a2a(pr, po, rcounts, counts)
-            xr, yr, vr = self.part.unpack(pr)
+            if not hasattr(self.shard, "apply_packed"):
+                xr, yr, vr = self.part.unpack(pr)
         else:
             xr = torch.empty(nr, dtype=x.dtype, device=x.device)
             yr = torch.empty(nr, dtype=x.dtype, device=x.device)
@@ -343,7 +349,10 @@ class ShardedMatrix:
                 vr = torch.empty(nr, dtype=x.dtype, device=x.device)
                 self._a2a(vr, vo, rcounts, counts)
         outr = torch.empty(nr, dtype=x.dtype, device=x.device)
-        self.shard.apply(op, xr, yr, vr, outr)
+        if packed_path and hasattr(self.shard, "apply_packed"):
+            self.shard.apply_packed(op, pr, outr)            # the op kernels read the records in place
+        else:
+            self.shard.apply(op, xr, yr, vr, outr)
         back = torch.empty(x.numel(), dtype=x.dtype, device=x.device)
         self._a2a(back, outr, counts, rcounts)
         self.part.gather(back, perm, out)
@@ -413,7 +422,8 @@ class ShardedMatrix:
             if packed_path:
                 pr = torch.empty((nr, po.shape[1]), dtype=x.dtype, device=x.device)
                 self._a2a(pr, po, h.rcounts, h.counts)
-                h.xr, h.yr, h.vr = self.part.unpack(pr)
+                h.pr = pr if hasattr(self.shard, "apply_packed") else None
+                h.xr, h.yr, h.vr = (None, None, None) if h.pr is not None else self.part.unpack(pr)
                 h.keep = (x, y, v, po, pr)
             else:
                 h.xr = torch.empty(nr, dtype=x.dtype, device=x.device)
@@ -424,6 +434,7 @@ class ShardedMatrix:
                 if vv is not None:
                     h.vr = torch.empty(nr, dtype=x.dtype, device=x.device)
                     self._a2a(h.vr, vo, h.rcounts, h.counts)
+                h.pr = None
                 h.keep = (x, y, v, xo, yo, vo)
             h.outr = torch.empty(nr, dtype=x.dtype, device=x.device)
             h.ev_routed = comm.record_event() if comm is not None else None
@@ -434,10 +445,13 @@ class ShardedMatrix:
         if h.ev_routed is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(h.ev_routed)
-            for t in (h.xr, h.yr, h.vr, h.outr):
+            for t in (h.xr, h.yr, h.vr, h.pr, h.outr):
                 if t is not None:
                     t.record_stream(cur)                          # allocated under the communication stream
-        self.shard.apply(h.op, h.xr, h.yr, h.vr, h.outr)
+        if h.pr is not None:
+            self.shard.apply_packed(h.op, h.pr, h.outr)           # the op kernels read the records in place
+        else:
+            self.shard.apply(h.op, h.xr, h.yr, h.vr, h.outr)
         h.ev_applied = torch.cuda.current_stream().record_event() if h.ev_routed is not None else None
 
     def finish(self, h, out):

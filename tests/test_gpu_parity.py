@@ -399,6 +399,31 @@ def test_file_loader_windows_and_foreign_files(G, oracle_mod, tmp_path, monkeypa
         back.close()
 
 
+def test_apply_packed_records(G, oracle_mod):
+    """smatrix_apply_packed_dev: the op kernels read {x,y[,v]} records in place (what the sharded exchange
+    delivers); same results as the three-array form, growth rounds included"""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 300000
+    x = rng.integers(0, 4000, n, dtype=np.uint32); y = rng.integers(1, 9000, n, dtype=np.uint32)   # y >= 1: order independent
+    v = rng.integers(0, 5, n, dtype=np.uint32)
+    g, o = G(), oracle_mod.Oracle()
+    dev = torch.device("cuda", 0)
+    rec3 = torch.from_numpy(np.stack([x, y, v], 1).view(np.int32)).to(dev).contiguous()
+    rec2 = rec3[:, :2].contiguous()
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    for op in (2, 3, 1, 2):
+        g.m.apply_packed_dev(op, n, rec3.data_ptr(), 3, out.data_ptr(), None)
+        o.apply(op, x, y, v)
+        g.m.apply_packed_dev(0, n, rec2.data_ptr(), 2, out.data_ptr(), None)
+        assert (out.cpu().numpy().view(np.uint32) == o.apply(0, x, y)).all(), op
+    rows = np.unique(x)
+    assert g.m.rowlen_batch(rows).tolist() == [o.rowlen(int(r)) for r in rows]
+    with pytest.raises(ValueError):
+        g.m.apply_packed_dev(2, n, rec2.data_ptr(), 2, out.data_ptr(), None)   # a write needs {x,y,v}
+    g.close(); o.close()
+
+
 def test_sharded_path_one_rank_nccl():
     """the HIP partitioner + RCCL all_to_all + local shard with world_size 1 (all a 1-GPU box allows):
     bench.py --force-sharded must produce the same sane line as the direct path"""
