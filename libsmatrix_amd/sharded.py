@@ -281,6 +281,10 @@ class ShardedMatrix:
             for r, xs in enumerate(self._gather_obj(self.shard.displaced_rows(self.rank, self.world))):
                 for v in xs:
                     place[int(v)] = r
+            if len(place) > 512:
+                raise RuntimeError("%d rows live away from their equal-range owner and no stored placement was found "
+                                   "(%s): shard files written under a planned placement need their .placement file"
+                                   % (len(place), self.placement_file))
             pl = Placement(self.world, None, place)
         elif self.auto_place and self.world > 1:
             if x.numel():

@@ -82,6 +82,19 @@ fm.apply_dev(OP_GET, xs[0], ys[0], None, got)
 torch.cuda.synchronize()
 assert torch.equal(got, want * 2), "writes after the reopen did not reach the rows' owners"
 fm.close()
+# files written with EQUAL ranges and no stored placement (e.g. by an earlier version): reopened from where the rows are
+path2 = os.path.join(d[0], "eq%d.smx" % rank)
+os.environ["SMATRIX_SHARD_PLACE"] = "0"
+em = ShardedMatrix(shard=HipShard(path2))
+em.apply_dev(OP_INCR, xs[1], ys[1], ones, oi)
+em.apply_dev(OP_GET, xs[1], ys[1], None, want)
+em.close()
+os.remove(path2 + ".placement")
+os.environ["SMATRIX_SHARD_PLACE"] = "1"
+em = ShardedMatrix(shard=HipShard(path2))
+em.apply_dev(OP_GET, xs[1], ys[1], None, got)
+assert em.placement.cuts is None and not em.placement.place and torch.equal(got, want)
+em.close()
 dist.barrier()
 if rank == 0:
     import shutil
