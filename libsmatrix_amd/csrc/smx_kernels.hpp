@@ -65,10 +65,18 @@ static_assert(sizeof(SubCtr) == 64, "one sub-counter per 64-byte line");
 __host__ __device__ inline uint64_t block_units(uint32_t lg) {
   return units_of_lg(lg) + (lg >= BIG_LG ? SUB_UNITS : 0);
 }
+// Endgame: with little room left an even split leaves every sub-counter one or two tickets, the patient
+// retry (own share + three others) misses most of what remains, and the row bounces through one
+// re-partition round after the other before it finally grows.  Below SUBS_ENDGAME tickets the whole room
+// goes to sub-counter 0, which the patient path always tries last: the next round drains it exactly.
+#ifndef SMX_ENDGAME
+#define SMX_ENDGAME 8
+#endif
+constexpr uint32_t SUBS_ENDGAME = SMX_ENDGAME * SUBS;
 __host__ __device__ inline void subs_init(SubCtr* sc, uint32_t room) {
   for (uint32_t k = 0; k < SUBS; k++) {
     sc[k].cnt = 0;
-    sc[k].quota = room / SUBS + (k < room % SUBS ? 1u : 0u);
+    sc[k].quota = room < SUBS_ENDGAME ? (k == 0 ? room : 0u) : room / SUBS + (k < room % SUBS ? 1u : 0u);
   }
 }
 
@@ -216,7 +224,7 @@ __device__ inline uint32_t* sub_ticket(SubCtr* sc) {
 __device__ inline uint32_t* sub_ticket_elsewhere(SubCtr* subs, uint32_t k0) {
   for (uint32_t a = 1; a < 4; a++)
     if (uint32_t* t = sub_ticket(subs + ((k0 + a * (SUBS / 4u)) & (SUBS - 1u)))) return t;
-  return nullptr;
+  return sub_ticket(subs);                       // the endgame pool (see subs_init)
 }
 
 // The per-op body: returns the op's result (new value for writers); *deferred is set when a
