@@ -219,8 +219,10 @@ __device__ inline uint32_t* sub_ticket(SubCtr* sc) {
 }
 // Own share exhausted: three more at stride SUBS/4.  With >= SUBS/4 tickets of room left some share on
 // that stride still has one, so a nearly full row does not bounce its ops through re-partition rounds.
-// Only the small-batch kernel (k_apply: retry rounds, scalar calls) is PATIENT; in the aggregating
-// kernel the extra code cost 0.4 ms per 2^24-op batch.
+// The retry is on the slow path of both op kernels (PATIENT).  In the aggregating kernel it once cost
+// 0.4 ms per 2^24-op batch -- 82 SGPRs, over the residency cliff -- and is affordable since the kernel
+// is pinned to 80 SGPRs (it now compiles to 78 SGPRs / 58 VGPRs, still 8 waves per SIMD): fewer ops of
+// big rows are deferred for nothing, 2.71 -> 2.68 ms per step (SMX_AGG_PATIENT).
 __device__ inline uint32_t* sub_ticket_elsewhere(SubCtr* subs, uint32_t k0) {
   for (uint32_t a = 1; a < 4; a++)
     if (uint32_t* t = sub_ticket(subs + ((k0 + a * (SUBS / 4u)) & (SUBS - 1u)))) return t;
@@ -390,6 +392,9 @@ __global__ void k_scalar(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t 
 //   phase 3  every op returns  old + prefix + v  (incr)  /  old - prefix - v  (decr)
 // -- the values a serial execution of the tile's ops in LDS-arrival order returns, i.e. a legal
 // serialisation.  Keys with y == 0 (quirk path) and the all-ones key take the per-op body.
+#ifndef SMX_AGG_PATIENT
+#define SMX_AGG_PATIENT true
+#endif
 #ifndef SMX_AGG_OPT
 #define SMX_AGG_OPT 2
 #endif
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       if (!(have & (1u << q))) continue;
       bool deferred = false;
       if (!(fast & (1u << q))) {
-        uint32_t res = apply_one<OP>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred);
+        uint32_t res = apply_one<OP, SMX_AGG_PATIENT>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred);
         old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
       }
       l_sum[hh[q]] = old[q];                                  // the cell's value before the tile
