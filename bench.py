@@ -207,15 +207,15 @@ def main():
         comm = ThreadPoolExecutor(max_workers=1, initializer=lambda: torch.cuda.set_device(local))
 
     def step_threaded(s):
-        f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones)
-        f_g = comm.submit(m.route, OP_GET, xs[s], ys[s])           # travels under the incr kernels of s
+        f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones, True)
+        f_g = comm.submit(m.route, OP_GET, xs[s], ys[s], None, True)           # travels under the incr kernels of s
         h_i = f_i.result()
         m.apply_routed(h_i)
         f_fi = comm.submit(m.finish, h_i, out_i)
         h_g = f_g.result()
         m.apply_routed(h_g)
         if s + 1 < total_steps and s + 1 != args.warmup:           # never across the timing fence
-            pending[s + 1] = comm.submit(m.route, OP_INCR, xs[s + 1], ys[s + 1], ones)
+            pending[s + 1] = comm.submit(m.route, OP_INCR, xs[s + 1], ys[s + 1], ones, True)
         f_fg = comm.submit(m.finish, h_g, out_g)
         f_fi.result(); f_fg.result()
         m.wait(h_i); m.wait(h_g)
@@ -225,13 +225,13 @@ def main():
             return step_threaded(s)
         if sharded and not args.no_overlap:
             # exchange of get(s) overlaps the incr kernels of s; exchange of incr(s+1) overlaps get(s)
-            h_i = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones)
-            h_g = m.route(OP_GET, xs[s], ys[s])
+            h_i = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones, True)
+            h_g = m.route(OP_GET, xs[s], ys[s], None, True)
             m.apply_routed(h_i)                                   # host-driven rounds; get(s) records travel meanwhile
             m.finish(h_i, out_i)
             m.apply_routed(h_g)                                   # one async launch: runs while the host sits in the next route()
             if s + 1 < total_steps and s + 1 != args.warmup:      # never across the timing fence
-                pending[s + 1] = m.route(OP_INCR, xs[s + 1], ys[s + 1], ones)
+                pending[s + 1] = m.route(OP_INCR, xs[s + 1], ys[s + 1], ones, True)
             m.finish(h_g, out_g)
             m.wait(h_i); m.wait(h_g)
         elif sharded:

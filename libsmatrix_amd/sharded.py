@@ -403,14 +403,16 @@ class ShardedMatrix:
             self._comm_stream = torch.cuda.Stream(device=like.device)
         return self._comm_stream
 
-    def route(self, op, x, y, v=None):
+    def route(self, op, x, y, v=None, inputs_ready=False):
+        """inputs_ready: the caller guarantees that x, y, v are complete (e.g. produced before an earlier
+        synchronisation) -- the exchange then does not wait for whatever the compute stream is running now."""
         h = self._Routed()
         h.op, h.n, h.x_dev = op, x.numel(), x.device
         comm = self._comm(x)
         vv = None if op == OP_GET else v
         self._ensure_placement(x, op != OP_GET)
         ctx = torch.cuda.stream(comm) if comm is not None else _null_ctx()
-        if comm is not None:
+        if comm is not None and not inputs_ready:
             comm.wait_stream(torch.cuda.current_stream())         # inputs were produced on the compute stream
         with ctx:
             packed_path = self.packed and hasattr(self.part, "partition_packed")
