@@ -10,10 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("packed,split,place,world", [("0", "0", "1", 2), ("1", "0", "1", 2), ("1", "1", "1", 2),
-                                                      ("1", "1", "0", 2), ("1", "0", "1", 4)])
+                                                      ("1", "1", "0", 2), ("1", "0", "1", 4), ("1", "1", "1", 8)])
 def test_sharded_ranks_gloo(packed, split, place, world):
     """place=1: skew-aware placement planned from the first batch (hot rows one by one + unequal hash
-    ranges); place=0: equal hash ranges.  world 4 exercises more than one cut point."""
+    ranges); place=0: equal hash ranges.  world 4 and 8 (the node size the bench is scaled to) exercise several cut points."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", SMX_TEST_PACKED=packed, SMX_TEST_SPLIT=split, SMX_TEST_PLACE=place)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(29533 + int(packed) + 2 * int(split) + 4 * int(place) + 8 * world),
