@@ -699,18 +699,26 @@ def test_sharded_two_ranks_one_gpu():
     assert p.returncode == 0 and "SHARDED_2RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
-def test_bench_launch_contract_two_ranks():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launch_contract_n_ranks(world):
     """the driver's N>1 launch line (torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE from the env, ONE JSON
-    line from rank 0) on the 1-GPU rig: both ranks on cuda:0, gloo, host-staged exchange"""
+    line from rank 0) on the 1-GPU rig: all ranks on cuda:0, gloo, host-staged exchange.  At 8 ranks (the node
+    size of the scaling run) the planned placement must leave every shard within 10 % of the mean load --
+    equal hash ranges put 1.9x the mean on the owner of the hottest row."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-lg", "18", "--backend", "gloo", "--single-device"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29611 + world), os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch-lg", "18" if world == 2 else "20",
+           "--backend", "gloo", "--single-device"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak" and res["sanity_all_gets_positive"]
+    assert res["n_gpus"] == world and res["steps"] == 3 and res["scaling"] == "weak" and res["sanity_all_gets_positive"]
     assert res["value"] > 0 and "roofline" in res
+    pl = res["config"]["placement"]
+    assert pl["rows_placed_by_load"] > 0 and len(pl["ops_applied_over_mean"]) == world
+    if world == 8:
+        assert max(pl["ops_applied_over_mean"]) < 1.10, pl
