@@ -126,6 +126,11 @@ class HipShard:
         if x.numel():
             self.m.rowlen_batch_dev(x.numel(), x.data_ptr(), out.data_ptr(), _stream())
 
+    def getrow(self, x, offsets, pairs, counts):
+        """offsets: int64 [n+1] (row r may receive offsets[r+1]-offsets[r] pairs), pairs: int32 [total, 2]"""
+        if x.numel():
+            self.m.getrow_batch_dev(x.numel(), x.data_ptr(), offsets.data_ptr(), pairs.data_ptr(), counts.data_ptr(), _stream())
+
     def close(self):
         self.m.close()
 
@@ -381,6 +386,59 @@ class ShardedMatrix:
         self._a2a(back, lr, counts, rcounts)
         self.part.gather(back, perm, out)
         return out
+
+    def getrow_dev(self, xs):
+        """getrow of arbitrary rows (include/smatrix.h smatrix_getrow, batched): every row is read on its owner in
+        slot order and sent back.  -> (offsets int64 [n+1], pairs int32 [total, 2] = {y, value}, counts int32 [n]);
+        row i's pairs are pairs[offsets[i] : offsets[i] + counts[i]] (counts[i] == offsets[i+1] - offsets[i]).
+        COLLECTIVE.  A scan of a rank's OWN rows (local.getrow_batch) needs no exchange at all."""
+        dev = xs.device
+        self._ensure_placement(xs, False)
+        counts, perm, xo, _, _ = self.part.partition(xs, xs, None, self.world)
+        send = torch.tensor(counts, dtype=torch.int64, device=dev)
+        recv = torch.empty(self.world, dtype=torch.int64, device=dev)
+        self._a2a(recv, send)
+        rcounts = [int(c) for c in recv.tolist()]
+        nr = sum(rcounts)
+        xr = torch.empty(nr, dtype=xs.dtype, device=dev)
+        self._a2a(xr, xo, rcounts, counts)
+        # owners: lengths, then the rows themselves into one buffer (capacity = rowlen: all pairs, no Q5 overrun)
+        lr = torch.empty(nr, dtype=torch.int32, device=dev)
+        self.shard.rowlen(xr, lr)
+        offr = torch.zeros(nr + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lr.to(torch.int64), 0, out=offr[1:])
+        tot_r = int(offr[-1].item()) if nr else 0
+        pr = torch.empty((tot_r, 2), dtype=torch.int32, device=dev)
+        cr = torch.zeros(nr, dtype=torch.int32, device=dev)
+        self.shard.getrow(xr, offr, pr, cr)
+        # back: the lengths (row order of the partition), then the pairs, split by requesting rank
+        lens_p = torch.empty(xs.numel(), dtype=torch.int32, device=dev)
+        self._a2a(lens_p, cr, counts, rcounts)
+        bounds = [0]
+        for c in rcounts:
+            bounds.append(bounds[-1] + c)
+        psend = [int((offr[bounds[i + 1]] - offr[bounds[i]]).item()) for i in range(self.world)] if nr else [0] * self.world
+        ps = torch.tensor(psend, dtype=torch.int64, device=dev)
+        prcv = torch.empty(self.world, dtype=torch.int64, device=dev)
+        self._a2a(prcv, ps)
+        precv = [int(c) for c in prcv.tolist()]
+        pairs_p = torch.empty((sum(precv), 2), dtype=torch.int32, device=dev)
+        self._a2a(pairs_p, pr, precv, psend)
+        # un-permute: row i of the request sits at position perm[i] of the partitioned order
+        lens = torch.empty_like(lens_p)
+        self.part.gather(lens_p, perm, lens)
+        offsets = torch.zeros(xs.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens.to(torch.int64), 0, out=offsets[1:])
+        off_p = torch.zeros(xs.numel() + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(lens_p.to(torch.int64), 0, out=off_p[1:])
+        total = int(offsets[-1].item()) if xs.numel() else 0
+        pairs = torch.empty((total, 2), dtype=torch.int32, device=dev)
+        if total:
+            # pair k of the output belongs to request row i = row_of[k]; it is pair (k - offsets[i]) of partitioned row perm[i]
+            row_of = torch.repeat_interleave(torch.arange(xs.numel(), device=dev), lens.to(torch.int64))
+            src = off_p[perm.long()[row_of]] + (torch.arange(total, device=dev) - offsets[row_of])
+            pairs.copy_(pairs_p[src])
+        return offsets, pairs, lens
 
     # ---- split-phase form: lets the exchange of one batch overlap the op kernels of another -------
     #

@@ -52,6 +52,17 @@ if mine.numel():
     l = torch.empty(mine.numel(), dtype=torch.int32, device=dev)
     sm.local.rowlen_batch_dev(mine.numel(), mine.contiguous().data_ptr(), l.data_ptr(), st); torch.cuda.synchronize()
     assert int((l > 0).all()), "an owned row is missing from the local shard"
+# getrow of arbitrary rows, routed to the owners: the same cells as the un-sharded matrix holds (slot order is the owner's)
+qrows = rows[:300].contiguous()
+off, prs, cnt = sm.getrow_dev(qrows)
+torch.cuda.synchronize()
+doff, dpairs, dcnt = direct.getrow_batch(qrows.cpu().numpy().view("uint32"))
+assert cnt.cpu().tolist() == dcnt.tolist()
+pc, oc = prs.cpu().numpy().view("uint32"), off.cpu().tolist()
+for i in range(qrows.numel()):
+    a = sorted(map(tuple, pc[oc[i]: oc[i] + int(cnt[i])].tolist()))
+    b = sorted(map(tuple, dpairs[int(doff[i]): int(doff[i]) + int(dcnt[i])].tolist()))
+    assert a == b, "getrow of row %d differs" % int(qrows[i])
 # skew-aware placement was planned from the first batch: hot rows placed one by one, unequal hash ranges
 assert sm.placement.place and sm.placement.cuts is not None
 share = torch.tensor([float(sm.exchanged_ops)]); tot_ops = share.clone(); dist.all_reduce(tot_ops)

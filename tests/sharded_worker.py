@@ -97,6 +97,13 @@ class OracleShard:
         xs = x.numpy().view(np.uint32)
         out.copy_(torch.tensor([self.m.rowlen(int(v)) for v in xs], dtype=torch.int64).to(torch.int32))
 
+    def getrow(self, x, offsets, pairs, counts):
+        xs = x.numpy().view(np.uint32)
+        for i, v in enumerate(xs.tolist()):
+            row = self.m.getrow(v, int(offsets[i + 1] - offsets[i]) * 8)
+            pairs[int(offsets[i]): int(offsets[i]) + row.shape[0]] = torch.from_numpy(row.view(np.int32))
+            counts[i] = row.shape[0]
+
     def close(self):
         self.m.close()
 
@@ -157,6 +164,14 @@ def main():
     lens = torch.empty_like(q)
     sm.rowlen_dev(q, lens)
     assert lens.tolist() == [ref.rowlen(int(v)) for v in q.numpy().view(np.uint32)]
+    # getrow of arbitrary rows: read on the owners in slot order, same pairs as the single matrix holds
+    qg = q[:400]
+    off, prs, cnt = sm.getrow_dev(qg)
+    assert cnt.tolist() == lens[:400].tolist()
+    for i, xv in enumerate(qg.numpy().view(np.uint32).tolist()):
+        mine = prs[int(off[i]): int(off[i]) + int(cnt[i])].numpy().view(np.uint32)
+        want_row = ref.getrow(xv, ref.rowlen(xv) * 8)
+        assert sorted(map(tuple, mine.tolist())) == sorted(map(tuple, want_row.tolist())), xv
     # every row lives on exactly its owner, with the same length as in the single matrix
     rows = sm.shard.m.list_rows()
     assert (owner_np(rows, world, sm.placement) == rank).all(), "a row landed on the wrong shard"
