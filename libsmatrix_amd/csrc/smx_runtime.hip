@@ -219,6 +219,7 @@ struct Matrix {
   DevBuf<GrowTask> tasks;
   uint64_t io_window = 256ull << 20;    // bytes per window of the file loader / writer
   uint32_t in_stride = 1;               // words between consecutive ops of the batch being applied (3 / 2: packed records)
+  uint32_t prep_blocks = 512;           // grid cap of k_prep (it loops): most launches have far fewer deferred ops than the batch had ops
   unsigned io_threads = 16;             // host threads of the file loader / writer (SMATRIX_IO_THREADS; 1 = the serial code)
   DevBuf<uint32_t> klist;               // growth tasks of kind k at [k * klist_cap, ...), k = 0..2
   uint32_t klist_cap = 0;
@@ -450,7 +451,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
-    hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), 2048)), dim3(PREP_THREADS), 0, s,
+    hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                        (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
                        m->rebal.p, m->fl, m->in_stride);
@@ -577,6 +578,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
   m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
   if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
