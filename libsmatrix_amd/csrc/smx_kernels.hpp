@@ -120,7 +120,7 @@ struct GrowTask {
   uint32_t count;        // non-empty cells moved (becomes `used`, src/smatrix.c:410)
   uint32_t chunk0;       // first 64-slot chunk of the old table in the flat chunk space
   uint32_t chunk0_new;   // same for the new table
-  uint32_t dup;          // the old table holds one key twice (see k_grow_fixdup)
+  uint32_t dup;          // the old table holds one key twice (see grow_fixdup_one)
 };
 
 // How a row is doubled: tables whose old cells and new slots fit in LDS are rebuilt there by one wave
@@ -134,11 +134,13 @@ __host__ __device__ inline uint32_t grow_kind(uint32_t old_lg) {
   return old_lg <= GROW_LG0 ? 0u : old_lg <= GROW_LG1 ? 1u : old_lg <= GROW_LG2 ? 2u : GROW_CHUNKED;
 }
 
-// A kernel body runs either as its own launch (one workgroup per blockIdx) or as one phase of the
-// persistent round kernel (k_rounds), which gives every resident workgroup a share of a VIRTUAL grid.
+// Kernel bodies are device functions over a VIRTUAL grid (workgroup `bid` of `nb`) so that several of
+// them can be composed into one launch; each has a thin __global__ wrapper with the launch's own grid.
+// (A persistent kernel that ran all of them as phases between grid barriers was built, measured and
+// dropped -- DESIGN.md "Measured and rejected".)
 struct VGrid { uint32_t bid, nb; };
 #define SMX_VG (VGrid{blockIdx.x, gridDim.x})
-// counters other workgroups have just written (phases of one launch are separated by grid syncs)
+// control-block counters are read with agent-scope loads (they are written by atomics of earlier launches)
 __device__ inline uint32_t aload(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline uint64_t aload(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -185,18 +187,6 @@ __device__ inline DirSlot* dir_find(DirSlot* dir, uint32_t dmask, uint32_t x, ui
     if (s.y == x) { *snap = s; return &dir[h]; }
     h = (h + 1) & dmask;
   }
-}
-
-// Wave-aggregated append of `idx` to a list (one atomic per wave).
-__device__ inline void list_push(uint32_t* counter, uint32_t* list, uint32_t idx, bool want) {
-  uint64_t m = __ballot(want);
-  if (m == 0) return;
-  uint32_t lane = __lane_id();
-  uint32_t leader = __ffsll((unsigned long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (want) list[base + __popcll(m & ((1ull << lane) - 1))] = idx;
 }
 
 // ---- op kernel ----------------------------------------------------------------
