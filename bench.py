@@ -95,6 +95,63 @@ def cpu_baseline(sample_ops, torch, dev):
         m.close()
         res["threads_8"] = {"value": round(2 * n8 / t8 / 1e6, 3), "unit": "Mops/s", "cores": T,
                             "sample": "first %d ops, each batch split over 8 threads: %.2fs" % (n8, t8)}
+        # T = all physical cores.  The reference's spin locks scale NEGATIVELY under Zipf (one global
+        # reader count + per-row mutexes, src/smatrix.c:843-889), so the sample is kept small: 2^22 ops
+        try:
+            import psutil
+            T = psutil.cpu_count(logical=False) or os.cpu_count()
+        except Exception:
+            T = os.cpu_count()
+        nall = min(sample_ops, 1 << 22)
+        m = O.Reference()
+        xs, ys = x[:nall], y[:nall]
+        ones = np.ones(nall, np.uint32)
+        per = (nall + T - 1) // T
+        tall = 0.0
+        for op in (O.OP_INCR, O.OP_GET):
+            th = [threading.Thread(target=m.apply, args=(op, xs[i * per:(i + 1) * per], ys[i * per:(i + 1) * per],
+                                                         ones[i * per:(i + 1) * per])) for i in range(T)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            tall += time.perf_counter() - t0
+        m.close()
+        res["threads_all_physical"] = {"value": round(2 * nall / tall / 1e6, 3), "unit": "Mops/s", "cores": T,
+                                       "sample": "first %d ops split over %d threads (thread start inside the timed region, "
+                                                 "src/smatrix_benchmark.c:109-122): %.2fs" % (nall, T, tall)}
+    # BASELINE config 1 (CPU-only configuration): (a) the stock benchmark pattern, 1 036 288 incr then get, T = 1
+    # (src/smatrix_benchmark.c:29-65); (b) 1 M uniform-random ops over 2^20 x 2^20 ids, incr batch then get batch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from smatrix_benchmark import pattern
+    c1 = {}
+    px, py = pattern(0, 1024)
+    m = O.Reference() if kind == "reference" else O.Oracle()
+    ones = np.ones(px.size, np.uint32)
+    t0 = time.perf_counter(); m.apply(O.OP_INCR, px, py, ones); t1 = time.perf_counter(); m.apply(O.OP_GET, px, py); t2 = time.perf_counter()
+    m.close()
+    c1["stock_pattern_T1"] = {"ops": int(px.size), "incr_ms": (t1 - t0) * 1e3, "get_ms": (t2 - t1) * 1e3,
+                              "incr_Mops": px.size / (t1 - t0) / 1e6, "get_Mops": px.size / (t2 - t1) / 1e6}
+    ug = Stream("uniform", SEED, 1 << 20, 1.1, 0)
+    ux, uy = ug.fill(0, 1000000)
+    ug.close()
+    m = O.Reference() if kind == "reference" else O.Oracle()
+    ones = np.ones(ux.size, np.uint32)
+    t0 = time.perf_counter(); m.apply(O.OP_INCR, ux, uy, ones); t1 = time.perf_counter(); want = m.apply(O.OP_GET, ux, uy); t2 = time.perf_counter()
+    rows_u = m.num_rows()
+    m.close()
+    c1["uniform_1m_T1"] = {"ops": 1000000, "incr_Mops": 1.0 / (t1 - t0), "get_Mops": 1.0 / (t2 - t1), "rows": rows_u,
+                           "sum_get": int(want.astype(np.uint64).sum())}
+    # the same two workloads through the HIP library's host-pointer batch API (PCIe copies included), checked against the CPU
+    from libsmatrix_amd import SparseMatrix
+    g = SparseMatrix()
+    ones = np.ones(ux.size, np.uint32)
+    g.incr_batch(ux[:1000], uy[:1000] + (1 << 21), ones[:1000])                     # first-call set-up outside the timing
+    t0 = time.perf_counter(); g.incr_batch(ux, uy, ones); t1 = time.perf_counter(); got = g.get_batch(ux, uy); t2 = time.perf_counter()
+    g.close()
+    c1["uniform_1m_hip_host_api"] = {"incr_Mops": 1.0 / (t1 - t0), "get_Mops": 1.0 / (t2 - t1), "equals_cpu": bool((got == want).all())}
+    res["config1"] = c1
     return res
 
 
@@ -123,6 +180,271 @@ def random_access_roofline(torch, dev, gib=4, touches=1 << 27):
     return out
 
 
+CF_COLS, CF_PER_ROW = 13000000, 115          # config 3 / 5 shape, SURVEY.md 8(d)
+BYTES_NNZ, BYTES_ROW = 16, 24                # getrow: 8 B cell read + 8 B pair written per nnz; 4 B id + 16 B directory slot + 4 B count per row
+
+
+def kernel_source_sha16():
+    """identifies the kernels a PMC profile was taken with (profiles/*_pmc.json carries the same hash)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("smx_kernels.hpp", "smx_runtime.hip"):
+        h.update(open(os.path.join(ROOT, "libsmatrix_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def verify_config2(torch, dev, xs_ring, ys_ring, B, n_ring):
+    """Parity inside the bench, against numbers the REFERENCE produced (compiled reference, 263 s on
+    one CPU thread): a fresh matrix takes exactly the first 4e8 ops of the stream; after 10^7 ops the sum over the
+    stream of get(x_i,y_i) must be 52 480 898 544 with 561 596 rows / 4 463 637 nnz, after 4e8 ops the matrix must
+    hold exactly 1 000 000 rows, 100 401 767 nnz and a hottest row of 935 410 columns."""
+    from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
+    stream = torch.cuda.current_stream().cuda_stream
+    m = SparseMatrix()
+    gen = Stream("zipf", SEED, N_IDS, ZIPF_S, 1)
+    ones = torch.ones(B, dtype=torch.int32, device=dev)
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+    xt = torch.empty(B, dtype=torch.int32, device=dev); yt = torch.empty_like(xt)
+
+    def batch(s):
+        if s < n_ring:
+            return xs_ring[s], ys_ring[s]
+        gen.fill_device(s * B, B, xt.data_ptr(), yt.data_ptr(), stream)
+        return xt, yt
+
+    def incr(x, y, a, b):
+        if b > a:
+            m.apply_batch_dev(OP_INCR, b - a, x[a:b].data_ptr(), y[a:b].data_ptr(), ones.data_ptr(), out.data_ptr(), stream)
+
+    def census():
+        ids = torch.arange(1, N_IDS + 1, dtype=torch.int64, device=dev)
+        h = ids ^ (ids >> 16); h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        h = h ^ (h >> 16)                                                    # fmix32(rank): the scrambled row ids
+        rows = torch.where(h >= 2 ** 31, h - 2 ** 32, h).to(torch.int32)
+        lens = torch.empty(N_IDS, dtype=torch.int32, device=dev)
+        m.rowlen_batch_dev(N_IDS, rows.data_ptr(), lens.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return int(m.stats()["rows"]), int(lens.sum(dtype=torch.int64).item()), int(lens.max().item())
+
+    res = {}
+    P1, P2 = 10000000, 400000000
+    assert P1 <= B
+    pos = 0
+    for s in range((P2 + B - 1) // B):
+        x, y = batch(s)
+        lo, hi = s * B, min(s * B + B, P2)
+        for cut in [c for c in (P1,) if lo < c < hi] + [hi]:
+            incr(x, y, pos - lo, cut - lo)
+            pos = cut
+            if cut == P1:                               # get over the first 10^7 ops of the stream (all inside batch 0)
+                m.apply_batch_dev(OP_GET, P1, x.data_ptr(), y.data_ptr(), None, out.data_ptr(), stream)
+                torch.cuda.synchronize()
+                sum_get = int(out[:P1].sum(dtype=torch.int64).item())
+                res["at_1e7_ops"] = dict(zip(("rows", "nnz", "max_rowlen"), census()), sum_get=sum_get)
+    res["at_4e8_ops"] = dict(zip(("rows", "nnz", "max_rowlen"), census()))
+    m.close(); gen.close()
+    want = {"at_1e7_ops": {"rows": 561596, "nnz": 4463637, "max_rowlen": 159472, "sum_get": 52480898544},
+            "at_4e8_ops": {"rows": 1000000, "nnz": 100401767, "max_rowlen": 935410}}
+    res["matches_reference"] = res["at_1e7_ops"] == want["at_1e7_ops"] and res["at_4e8_ops"] == want["at_4e8_ops"]
+    res["reference_figures"] = "SURVEY.md A.4 (compiled reference, this stream)"
+    assert res["matches_reference"], (res, want)
+    return res
+
+
+def build_cf(torch, dev, m, rows, chunk_rows=1 << 17):
+    """config 3 / 5 table: `rows` rows x 115 ops, uniform columns over 13 M, scrambled ids (SMX_DIST_CF), generated on the device"""
+    from libsmatrix_amd import Stream, OP_INCR
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = Stream("cf", SEED, CF_COLS, float(CF_PER_ROW), 1)
+    n_max = chunk_rows * CF_PER_ROW
+    x = torch.empty(n_max, dtype=torch.int32, device=dev); y = torch.empty_like(x)
+    ones = torch.ones_like(x); out = torch.empty_like(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r0 in range(0, rows, chunk_rows):
+        n = (min(rows, r0 + chunk_rows) - r0) * CF_PER_ROW
+        gen.fill_device(r0 * CF_PER_ROW, n, x.data_ptr(), y.data_ptr(), stream)
+        m.apply_batch_dev(OP_INCR, n, x.data_ptr(), y.data_ptr(), ones.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gen.close()
+    return dt
+
+
+def cf_row_ids(torch, dev, rows, shuffle=True):
+    ids = torch.arange(1, rows + 1, dtype=torch.int64, device=dev)
+    h = ids ^ (ids >> 16); h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    xs = torch.where(h >= 2 ** 31, h - 2 ** 32, h).to(torch.int32)
+    if shuffle:                                        # scan order != creation order
+        g = torch.Generator(device=dev); g.manual_seed(SEED)
+        xs = xs[torch.randperm(rows, device=dev, generator=g)]
+    return xs.contiguous()
+
+
+def scan_cf(torch, dev, m, rows, reps=5):
+    """rowlen_batch + getrow_batch over ALL rows (the reference's caller idiom: rowlen, buffer, getrow --
+    src/smatrix_jni.c:130-139); HIP events on the stream the kernels are launched on"""
+    stream = torch.cuda.current_stream().cuda_stream
+    xs = cf_row_ids(torch, dev, rows)
+    lens = torch.empty(rows, dtype=torch.int32, device=dev)
+    best = None
+    for rep in range(reps):
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        e0.record()
+        m.rowlen_batch_dev(rows, xs.data_ptr(), lens.data_ptr(), stream)
+        e1.record()
+        if rep == 0:
+            off = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(lens.long() + 1, 0, out=off[1:])
+            ret = torch.zeros((int(off[-1].item()), 2), dtype=torch.int32, device=dev)
+            cnt = torch.empty(rows, dtype=torch.int32, device=dev)
+        e2.record()
+        m.getrow_batch_dev(rows, xs.data_ptr(), off.data_ptr(), ret.data_ptr(), cnt.data_ptr(), stream)
+        e3.record()
+        torch.cuda.synchronize()
+        t = (e0.elapsed_time(e1), e2.elapsed_time(e3))
+        if best is None or t[1] < best[1]:
+            best = t
+    nnz = int(cnt.sum(dtype=torch.int64).item())
+    ok = bool((cnt == lens).all().item()) and int(ret[:, 1].sum(dtype=torch.int64).item()) == rows * CF_PER_ROW
+    ksum = int(ret[:, 0].sum(dtype=torch.int64).item())
+    st = m.stats()
+    table_bytes = (int(st["arena_units"]) - int(st["arena_free_units"])) * 128
+    alg = nnz * BYTES_NNZ + rows * BYTES_ROW
+    sec = best[1] * 1e-3
+    return {"rows": rows, "nnz": nnz, "verified_sum_of_values_eq_ops": ok, "key_checksum": ksum,
+            "rowlen_ms": best[0], "getrow_ms": best[1], "Gnnz_per_s": nnz / sec / 1e9, "Mrows_per_s": rows / sec / 1e6,
+            "roofline": {"bound": "hbm", "kernel": "k_getrow", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": best[1],
+                         "bytes_per_nnz": BYTES_NNZ, "bytes_per_row": BYTES_ROW,
+                         "bytes_moved_model": table_bytes + 8 * nnz + 24 * rows,
+                         "moved_GBps_model": (table_bytes + 8 * nnz + 24 * rows) / sec / 1e9,
+                         "note": "achieved = algorithmic 16 B/nnz + 24 B/row; the tables are <= 50 % full by the reference's growth "
+                                 "rule (src/smatrix.c:346), so the kernel has to MOVE table bytes + 8 B/nnz: moved_GBps_model"}}
+
+
+def run_config3(torch, dev, rows=13000000, reps=5):
+    from libsmatrix_amd import SparseMatrix
+    m = SparseMatrix()
+    build_s = build_cf(torch, dev, m, rows)
+    res = scan_cf(torch, dev, m, rows, reps)
+    res["build_s"] = build_s
+    res["build_Gops_per_s"] = rows * CF_PER_ROW / build_s / 1e9
+    res["workload"] = "config-3: smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz (CF shape), table built on the device" % (rows, res["nnz"])
+    m.close()
+    return res
+
+
+def run_config5(torch, dev, rows=None, path=None):
+    """config 5 on ONE GPU: persist the config-3 matrix (smatrix_close), reopen (bulk load), verify, re-bench get/getrow"""
+    import shutil, tempfile
+    from libsmatrix_amd import SparseMatrix, Stream, OP_GET
+    stream = torch.cuda.current_stream().cuda_stream
+    d = os.path.dirname(path) if path else tempfile.gettempdir()
+    free = shutil.disk_usage(d).free
+    if rows is None:
+        rows = 13000000 if free > 40e9 else max(int(free * 0.5 / 2100) // 100000 * 100000, 100000)
+    path = path or os.path.join(d, "smx_bench_config5_%d.smx" % os.getpid())
+    if os.path.exists(path):
+        os.remove(path)
+    m = SparseMatrix(path)
+    build_cf(torch, dev, m, rows)
+    before = scan_cf(torch, dev, m, rows, 1)
+    gen = Stream("cf", SEED, CF_COLS, float(CF_PER_ROW), 1)
+    n = 1 << 24
+    x = torch.empty(n, dtype=torch.int32, device=dev); y = torch.empty_like(x)
+    want = torch.empty_like(x); got = torch.empty_like(x)
+    gen.fill_device((rows // 2) * CF_PER_ROW, n, x.data_ptr(), y.data_ptr(), stream)
+    m.apply_batch_dev(OP_GET, n, x.data_ptr(), y.data_ptr(), None, want.data_ptr(), stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); m.close(); t_close = time.perf_counter() - t0
+    fbytes = os.path.getsize(path)
+    t0 = time.perf_counter(); m = SparseMatrix(path); t_open = time.perf_counter() - t0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    m.apply_batch_dev(OP_GET, n, x.data_ptr(), y.data_ptr(), None, got.data_ptr(), stream)
+    e1.record(); torch.cuda.synchronize()
+    after = scan_cf(torch, dev, m, rows, 3)
+    ok = bool(torch.equal(got, want)) and all(after[k] == before[k] for k in ("rows", "nnz", "key_checksum")) \
+        and after["verified_sum_of_values_eq_ops"] and int(m.stats()["rows"]) == rows
+    res = {"workload": "config-5 on one GPU: %d-row CF matrix persisted in the reference's file format, reopened, verified" % rows,
+           "rows": rows, "nnz": after["nnz"], "file_bytes": fbytes, "close_s": t_close, "write_GBps": fbytes / t_close / 1e9,
+           "open_s": t_open, "load_GBps": fbytes / t_open / 1e9, "verified": ok,
+           "get_after_reopen_Gops": n / (e0.elapsed_time(e1) * 1e-3) / 1e9, "getrow_after_reopen": after,
+           "scratch_free_bytes": free}
+    gen.close()
+    m.close()                       # nothing was written since the reload: close has nothing to persist
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+    return res
+
+
+
+def guarded(fn, *a):
+    """extra legs must never take the metric line down with them"""
+    try:
+        return fn(*a)
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def sustained_leg(torch, dev, m, gen, first_step, B, seconds, stream):
+    from libsmatrix_amd import OP_GET, OP_INCR
+    group = 32                                                # batches generated per untimed refill (4 GB of ids)
+    xs = torch.empty((group, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
+    ones = torch.ones(B, dtype=torch.int32, device=dev)
+    o1 = torch.empty(B, dtype=torch.int32, device=dev); o2 = torch.empty_like(o1)
+    busy, steps, s = 0.0, 0, first_step
+    while busy < seconds and steps < 4096:
+        for k in range(group):
+            gen.fill_device((s + k) * B, B, xs[k].data_ptr(), ys[k].data_ptr(), stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(group):
+            m.apply_batch_dev(OP_INCR, B, xs[k].data_ptr(), ys[k].data_ptr(), ones.data_ptr(), o1.data_ptr(), stream)
+            m.apply_batch_dev(OP_GET, B, xs[k].data_ptr(), ys[k].data_ptr(), None, o2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        busy += time.perf_counter() - t0
+        steps += group; s += group
+    st = m.stats()
+    return {"steps": steps, "timed_s": busy, "ms_per_step": busy / steps * 1e3, "Mops_per_s": 2 * B * steps / busy / 1e6,
+            "stream_ops_at_end": s * B, "rows": int(st["rows"]),
+            "note": "continues the config-2 stream past 4e8 ops in timed groups of %d steps (inputs generated between groups)" % group}
+
+
+def dense_ids_leg(torch, dev, B, stream, steps=24):
+    from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
+    gen = Stream("zipf", SEED, N_IDS, ZIPF_S, 0)
+    m = SparseMatrix()
+    xs = torch.empty((steps, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
+    for k in range(steps):
+        gen.fill_device(k * B, B, xs[k].data_ptr(), ys[k].data_ptr(), stream)
+    ones = torch.ones(B, dtype=torch.int32, device=dev)
+    o1 = torch.empty(B, dtype=torch.int32, device=dev); o2 = torch.empty_like(o1)
+    warm = 2
+    m.profile(True)
+    for k in range(steps):
+        if k == warm:
+            m.profile(True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.apply_batch_dev(OP_INCR, B, xs[k].data_ptr(), ys[k].data_ptr(), ones.data_ptr(), o1.data_ptr(), stream)
+        m.apply_batch_dev(OP_GET, B, xs[k].data_ptr(), ys[k].data_ptr(), None, o2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    ok = bool((o2 >= 1).all().item()) and int(st["rows"]) <= N_IDS
+    m.close(); gen.close()
+    n = steps - warm
+    return {"steps": n, "ms_per_step": dt / n * 1e3, "Mops_per_s": 2 * B * n / dt / 1e6, "rows": int(st["rows"]),
+            "incr_kernel_ms": st["kernel_ms_incr"] / max(st["kernel_launches_incr"], 1),
+            "get_kernel_ms": st["kernel_ms_get"] / max(st["kernel_launches_get"], 1), "sanity": ok,
+            "note": "same stream with id = rank (dense): row tables use the reference's identity hash y % size, so hot columns cluster"}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +461,12 @@ def main():
                     help="test rig: every rank uses cuda:0 and the exchange is staged through the host (gloo)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="route through ShardedMatrix even with one rank (exercises the exchange path)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+                    help="2 (default): the metric's workload; 3: getrow scan of the 13M-row CF matrix; 5: file round trip of it (one GPU)")
+    ap.add_argument("--rows", type=int, default=None, help="--config 3/5: rows of the CF matrix (default 13M)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="config 2 only: skip the legs that are not `value` (reference-checksum replay, sustained run, dense ids, configs 3/5)")
+    ap.add_argument("--sustain-s", type=float, default=1.5, help="seconds of the sustained (continuing-stream) leg")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +481,19 @@ def main():
         os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.config in (3, 5):
+        # the other single-GPU configurations of BASELINE.json, one JSON line each with their own roofline
+        if args.config == 3:
+            r = run_config3(torch, dev, args.rows or 13000000)
+            line = {"metric": "getrow full-row scan", "value": r["Gnnz_per_s"] * 1e3, "unit": "Mnnz/s", "ms_per_step": r["getrow_ms"]}
+        else:
+            r = run_config5(torch, dev, args.rows)
+            line = {"metric": "file-backed persist + reopen", "value": r["load_GBps"], "unit": "GB/s (bulk load)", "ms_per_step": r["open_s"] * 1e3}
+        line.update({"n_gpus": 1, "steps": 1, "warmup": 0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                     "dtype": "u32", "data": "synthetic", "config": {"workload": r["workload"]},
+                     "roofline": r.get("roofline") or r["getrow_after_reopen"]["roofline"], "detail": r})
+        print(json.dumps(line))
+        return
     sharded = world > 1 or args.force_sharded
     if sharded:
         import torch.distributed as dist
@@ -299,6 +640,17 @@ def main():
     # parity spot-check inside the bench: the last get batch must equal the last incr returns' per-key max
     ok = bool((out_g >= 1).all().item())
 
+    extras = {}
+    if not sharded and not args.no_extras and args.batch_lg == BATCH_LG:
+        # (1) the reference-held checksums of this very stream, on a fresh matrix (outside the timed region)
+        extras["reference_checksums"] = verify_config2(torch, dev, xs_all, ys_all, B, ring)
+        # (2) sustained leg: the SAME step on the continuing stream (fresh batches, table keeps growing) for >= 1 s of
+        #     back-to-back steps, so that the run holds a timed region far longer than any sampling period
+        extras["sustained"] = guarded(sustained_leg, torch, dev, m, gen, total_steps, B, args.sustain_s, stream)
+        # (3) dense ids (id = Zipf rank, no scramble): the reference's identity-hash tables cluster here
+        #     (displacement 10^3-10^4); secondary metric
+        extras["dense_ids"] = guarded(dense_ids_leg, torch, dev, B, stream)
+
     total_ops = 2 * B * args.steps * world
     res = {
         "metric": "mixed incr+get ops/s", "value": total_ops / dt / 1e6, "unit": "Mops/s",
@@ -314,6 +666,7 @@ def main():
     }
     if shard_info:
         res["config"]["placement"] = shard_info
+    res.update(extras)
     if rank == 0:
         ki = st["kernel_ms_incr"] / max(st["kernel_launches_incr"], 1)
         kg = st["kernel_ms_get"] / max(st["kernel_launches_get"], 1)
@@ -330,22 +683,32 @@ def main():
                                "unit": "GB/s", "frac": ach_g / HBM_PEAK_GBS, "traffic": None,
                                "avg_launch_ms": kg, "ops_per_launch": ops_g, "bytes_per_op": BYTES_GET,
                                "gops_per_s": ops_g / (kg * 1e-3) / 1e9 if kg else 0.0}
-        # HBM-side bytes per launch from the committed PMC passes of this same command (rocprofv3
-        # cannot be run from inside the measured process); null when the profile is absent
+        # HBM-side bytes per launch: PMC counters cannot be read from inside the measured process, so they come from
+        # the committed rocprofv3 --pmc passes of this same command -- but ONLY while that profile was taken with the
+        # kernels that are running now (source hash); otherwise null, never a stale number next to fresh timings
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if world == 1 and args.batch_lg == BATCH_LG:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))
+            if world == 1 and args.batch_lg == BATCH_LG and pmc.get("kernel_source_sha16") == kernel_source_sha16():
                 res["roofline"]["traffic"] = pmc["k_apply_agg_incr"]["bytes_per_launch"]
                 res["roofline_get"]["traffic"] = pmc["k_apply_get"]["bytes_per_launch"]
-                res["roofline"]["traffic_source"] = res["roofline_get"]["traffic_source"] = "profiles/r01_pmc_summary.txt"
+                res["roofline"]["memory_side_atomics"] = pmc["k_apply_agg_incr"].get("memory_side_atomics")
+                res["roofline"]["traffic_source"] = res["roofline_get"]["traffic_source"] = pmc.get("summary", "profiles/")
+            else:
+                res["roofline"]["traffic_note"] = "profiles/pmc.json was taken with other kernel sources (%s): traffic left null" % pmc.get("kernel_source_sha16")
         except Exception:
             pass
         if steady:
             res["steady_state_all_hits"] = steady
         res["table"] = {k: st[k] for k in ("rows", "dir_slots", "arena_units", "arena_mapped", "batches",
                                            "rounds", "deferred_ops", "rows_grown", "dir_grown")}
+        if world == 1 and not sharded and not args.no_extras:
+            del xs_all, ys_all
+            res["config3_getrow"] = guarded(run_config3, torch, dev)
+            res["config5_file_1gpu"] = guarded(run_config5, torch, dev)
         if world == 1:
             ra = random_access_roofline(torch, dev)
+            big = random_access_roofline(torch, dev, gib=32)
+            ra["table_sized_buffer_32gib"] = {k: v for k, v in big.items() if k.endswith("_per_s")}
             g_get = res["roofline_get"]["gops_per_s"]; g_inc = res["roofline"]["gops_per_s"]
             ra.update({
                 "get_gops_per_s": g_get, "incr_gops_per_s": g_inc,

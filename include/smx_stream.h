@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-enum { SMX_DIST_UNIFORM = 0, SMX_DIST_ZIPF = 1 };
+/* SMX_DIST_CF: the collaborative-filtering shape of BASELINE config 3: op i belongs to row
+ * 1 + i / per_row and names a uniform column, i.e. x = id(1 + i / per_row), y = id(1 + draw_i % n_ids)
+ * with ONE draw per op (draw i); `zipf_s` carries per_row (ops per row, e.g. 115.0). */
+enum { SMX_DIST_UNIFORM = 0, SMX_DIST_ZIPF = 1, SMX_DIST_CF = 2 };
 
 typedef struct smx_stream smx_stream_t;
 

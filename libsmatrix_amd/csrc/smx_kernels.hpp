@@ -642,14 +642,25 @@ __device__ __forceinline__ void prep_body(
         l_cnt[3] = 1;
       }
       __syncthreads();
-      // B3. claim {meta,x} in one CAS.  Losing the slot to ANOTHER row id is left to the next round
-      //     (the ops stay deferred), which keeps this step a single pass.
+      // B3. claim {meta,x} in one CAS.  A slot lost to ANOTHER row id is not a reason to wait for the next
+      //     round (K new ids with one first-empty slot would need K rounds -- ids with equal fmix32(x) & mask are
+      //     easy to craft): the lane walks on to the next slot that is empty or holds X, like the reference's
+      //     insert does under its lock (src/smatrix.c:677-693).  Load <= 1/2, so an empty slot always exists.
       bool won = false;
       uint32_t rank2 = 0;
       if (at_empty) {
         if (l_cnt[3] && (uint64_t)l_cnt[2] + rank < dir_limit) {
-          uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
-          won = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull, (unsigned long long)want) == 0;
+          const uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+          for (;;) {
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull, (unsigned long long)want);
+            if (prev == 0) { won = true; break; }
+            if ((uint32_t)(prev >> 32) == X) break;         // another workgroup created this very row meanwhile
+            do {
+              hh = (hh + 1) & dmask;
+            } while (ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh])) != 0 &&
+                     (uint32_t)(ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh])) >> 32) != X);
+            if (ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh])) != 0) break;   // it holds X
+          }
           if (won) rank2 = atomicAdd(&l_cnt[1], 1u);
         } else {
           ctl->dir_full = 1;                             // directory at its limit
@@ -1641,10 +1652,16 @@ __device__ inline uint32_t draw_id(int dist, uint32_t n_ids, const double* cdf, 
 
 __global__ __launch_bounds__(256) void k_stream_fill(int dist, uint64_t seed, uint32_t n_ids,
                                                      const double* cdf, int scramble, uint64_t first,
-                                                     uint64_t n, uint32_t* x, uint32_t* y) {
+                                                     uint64_t n, uint32_t* x, uint32_t* y, uint64_t per_row) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t op = first + i;
+  if (dist == 2) {                                   // SMX_DIST_CF: row 1 + op / per_row, one uniform column draw per op
+    const uint32_t row = 1u + (uint32_t)(op / per_row), col = 1u + (uint32_t)(splitmix_at(seed, op) % n_ids);
+    x[i] = scramble ? fmix32(row) : row;
+    y[i] = scramble ? fmix32(col) : col;
+    return;
+  }
   x[i] = draw_id(dist, n_ids, cdf, scramble, splitmix_at(seed, 2 * op));
   y[i] = draw_id(dist, n_ids, cdf, scramble, splitmix_at(seed, 2 * op + 1));
 }

@@ -244,6 +244,7 @@ struct Matrix {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
   std::string fname;
+  bool dirty = false;                   // file mode: something changed since the file was loaded / last written
 };
 
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
@@ -430,6 +431,7 @@ void grow_rows(Matrix* m, hipStream_t s) {
 void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t* y,
                const uint32_t* v, uint32_t* out, hipStream_t s) {
   if (n == 0) return;
+  m->dirty = true;
   m->defer[0].need(n);
   m->defer[1].need(n);
   if (op == OP_SET) m->cellp.need(n);
@@ -438,8 +440,11 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   uint32_t cur_n = n;
   const uint32_t* idx = nullptr;
   bool timed0 = m->profile;
+  uint32_t stalled = 0, rows_before = m->dir_used;
   for (uint32_t round = 0;; round++) {
-    if (round > 200) smx_die("write batch did not converge (corrupt row table?)");
+    // the loop ends when nothing is deferred; it is abandoned only when rounds stop making PROGRESS (a fixed cap
+    // would turn a slow but legal batch -- many new rows contending for one directory slot -- into an abort)
+    if (stalled > 8) smx_die("write batch did not converge (corrupt row table?)");
     const uint32_t dir_limit = m->dir_size / 2;
     const uint32_t room = dir_limit > m->dir_used ? dir_limit - m->dir_used : 0;
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
@@ -473,6 +478,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = m->h_ctl->n_defer;
     if (nd == 0) break;
+    const bool progress = nd < cur_n || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
+                          m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
+    stalled = progress ? 0 : stalled + 1;
+    rows_before = m->dir_used;
     m->st.deferred_ops += nd;
     if (m->h_ctl->n_tasks) grow_rows(m, s);
     if (m->h_ctl->n_rebal) {
@@ -604,7 +613,7 @@ void smatrix_close(smatrix_t* self) {
     set_device(m);
     {
       std::lock_guard<std::mutex> g(m->mu);
-      if (!m->fname.empty() && self->fd) {
+      if (!m->fname.empty() && self->fd && m->dirty) {     // a matrix that was only read has nothing to persist
         if (m->io_threads > 1) file_store(self, m);
         else file_store_serial(self, m);
       }
@@ -842,7 +851,7 @@ static uint32_t scalar_one_locked(smatrix_t* self, Matrix* m, int op, uint32_t x
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(s));
     if (!res[1]) {
-      if (op != OP_GET) m->st.batches++;
+      if (op != OP_GET) { m->st.batches++; m->dirty = true; }
       return res[0];
     }
   }
@@ -1115,7 +1124,8 @@ int smx_stream_fill_device(smx_stream_t* st, uint64_t first, size_t n, uint32_t*
     HIP_OK(hipMemcpy(st->d_cdf, st->cdf, (size_t)st->n_ids * sizeof(double), hipMemcpyHostToDevice));
   }
   hipLaunchKernelGGL(k_stream_fill, dim3(blocks_for(n)), dim3(256), 0, s, st->dist, st->seed,
-                     st->n_ids, st->d_cdf, st->scramble, first, (uint64_t)n, d_x, d_y);
+                     st->n_ids, st->d_cdf, st->scramble, first, (uint64_t)n, d_x, d_y,
+                     st->dist == SMX_DIST_CF ? (uint64_t)st->zipf_s : 1ull);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -29,6 +29,7 @@ uint32_t smx_fmix32(uint32_t h) {
 
 smx_stream_t* smx_stream_new(int dist, uint64_t seed, uint32_t n_ids, double zipf_s, int scramble) {
   if (n_ids == 0) return NULL;
+  if (dist == SMX_DIST_CF && !(zipf_s >= 1.0)) return NULL;      /* ops per row */
   smx_stream_t* s = calloc(1, sizeof *s);
   if (!s) return NULL;
   s->dist = dist;
@@ -79,6 +80,17 @@ static uint32_t draw_id(const smx_stream_t* s, uint64_t r) {
 }
 
 void smx_stream_fill(const smx_stream_t* s, uint64_t first, size_t n, uint32_t* x, uint32_t* y) {
+  if (s->dist == SMX_DIST_CF) {
+    const uint64_t per_row = (uint64_t)s->zipf_s;
+    for (size_t i = 0; i < n; i++) {
+      uint64_t op = first + i;
+      uint32_t row = 1u + (uint32_t)(op / per_row);
+      uint32_t col = 1u + (uint32_t)(smx_splitmix64_at(s->seed, op) % s->n_ids);
+      x[i] = s->scramble ? smx_fmix32(row) : row;
+      y[i] = s->scramble ? smx_fmix32(col) : col;
+    }
+    return;
+  }
   for (size_t i = 0; i < n; i++) {
     uint64_t op = first + i;
     x[i] = draw_id(s, smx_splitmix64_at(s->seed, 2 * op));

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib
 
-DIST = {"uniform": 0, "zipf": 1}
+DIST = {"uniform": 0, "zipf": 1, "cf": 2}     # "cf": zipf_s carries the ops per row (include/smx_stream.h)
 
 
 class Stream:

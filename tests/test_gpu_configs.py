@@ -1,0 +1,309 @@
+"""GPU (-m gpu): BASELINE.json's configs under the driver's eyes, pinned to numbers the REFERENCE holds.
+
+* config 2 -- the Zipf(1.1)^2 stream at 10^7 ops: SURVEY.md A.4 (measured on the compiled reference):
+  sum over the stream of get(x_i,y_i) = 52 480 898 544, 561 596 rows, 4 463 637 nnz, hottest row 159 472;
+  tests/test_oracle_golden.py holds the oracle to the same figures on the CPU.
+* config 3 -- the CF-recommender shape (13 M rows x ~115 nnz): oracle-compared at 1 M rows
+  (SURVEY.md 6 scale), properties + per-row oracle samples at the full 13 M rows (1.5 G nnz, 27 GB of row tables).
+* config 5 (one GPU's worth) -- that matrix closed, reopened and re-verified through the reference's file format.
+* parity holes of round 1: per-op return values of BATCHED incr/decr under heavy duplication (the LDS-folding
+  kernel), the reference's unchanged benchmark binary through the shim object, `self->mem`.
+All through the C ABI (ctypes); bit-exact."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from libsmatrix_amd.stream import Stream
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CF_COLS, CF_PER_ROW, SEED = 13000000, 115, 12345
+CF13M_NNZ = 1494993467   # distinct (row, column) cells of the 13 M-row CF stream (np.unique over the host generator, 500k rows at a time)
+
+
+@pytest.fixture(scope="module")
+def G():
+    from tests.gpu_adapter import GpuMatrix
+    import libsmatrix_amd
+    assert libsmatrix_amd.device_available(), "no HIP device: the product has no CPU fallback"
+    return GpuMatrix
+
+
+def per_key_sorted(x, y, ret):
+    k = x.astype(np.uint64) << 32 | y.astype(np.uint64)
+    o = np.lexsort((ret, k))
+    return k[o], ret[o]
+
+
+def expected_size(n):
+    """src/smatrix.c:346: a row that received n distinct keys (y >= 1) has the smallest 16*2^k slots with n <= 8*2^k + 1"""
+    size = 16
+    while n > size // 2 + 1:
+        size *= 2
+    return size
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_config2_reference_checksums_1e7(G):
+    """SURVEY.md A.4, numbers produced by the unmodified reference: 10^6 ops -> 576 561 nnz / 137 116 rows
+    (max row 28 558); 10^7 ops -> 4 463 637 nnz / 561 596 rows (max row 159 472), sum get = 52 480 898 544"""
+    gen = Stream("zipf", SEED, 1000000, 1.1, 1)
+    x, y = gen.fill(0, 10000000)
+    m = G()
+    ones = np.ones(1000000, np.uint32)
+    m.apply(2, x[:1000000], y[:1000000], ones)
+    rows = np.unique(x[:1000000])
+    lens = m.m.rowlen_batch(rows)
+    assert m.stats()["rows"] == rows.size == 137116
+    assert int(lens.astype(np.uint64).sum()) == 576561 and int(lens.max()) == 28558
+    rest = 9000000
+    m.apply(2, x[1000000:], y[1000000:], np.ones(rest, np.uint32))          # one 9M-op batch: the LDS-folding kernel
+    assert m.sum_get(x, y) == 52480898544
+    rows = np.unique(x)
+    lens = m.m.rowlen_batch(rows)
+    assert m.stats()["rows"] == rows.size == 561596
+    assert int(lens.astype(np.uint64).sum()) == 4463637 and int(lens.max()) == 159472
+    # every row's size is the reference's function of its rowlen (src/smatrix.c:346), checked on the getrow side too
+    off, pairs, cnt = m.m.getrow_batch(rows[:20000])
+    assert (cnt == lens[:20000]).all()
+    for r in (0, 1, 17, 4242, 19999):
+        assert m.row_info(int(rows[r])) == (expected_size(int(lens[r])), int(lens[r]))
+    m.close()
+    gen.close()
+
+
+def test_batched_returns_under_duplication(G, oracle_mod):
+    """k_apply_agg<INCR/DECR> (batches >= 1024 ops fold duplicate keys in LDS): the per-op RETURN values.
+    With one increment value per key the multiset of a key's returns is the same in every serialisation
+    (old + v, old + 2v, ...), so it must equal the oracle's; wrap-around below zero included."""
+    rng = np.random.default_rng(12)
+    g, o = G(), oracle_mod.Oracle()
+    for rnd, (op, n, nx, ny) in enumerate(((2, 50000, 50, 40), (3, 50000, 50, 40), (3, 70000, 50, 40),
+                                           (2, 1 << 20, 3000, 300), (3, 1 << 20, 3000, 300), (2, 4096, 2, 3))):
+        x = rng.integers(0, nx, n, dtype=np.uint32)
+        y = rng.integers(1, ny, n, dtype=np.uint32)
+        v = ((x * 7 + y * 13) % 5).astype(np.uint32)                          # one value per key, 0 included
+        v[(x + y) % 11 == 0] = 0xFFFFFFF0                                       # ... and near-wrap values
+        a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
+        ka, ra = per_key_sorted(x, y, a)
+        kb, rb = per_key_sorted(x, y, b)
+        assert (ra == rb).all(), (rnd, op)
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rnd
+    rows = o.list_rows().tolist()
+    for r in rows[:300]:
+        assert g.row_info(r) == o.row_info(r)
+    g.close(); o.close()
+
+
+def test_mixed_value_returns_contain_final_value(G, oracle_mod):
+    """mixed increments per key: the return multiset depends on the serialisation, but in EVERY serialisation
+    the last op of a key returns the key's final value -- so get(key) must be among the key's returns"""
+    rng = np.random.default_rng(3)
+    g = G()
+    n = 200000
+    for op in (2, 3, 2):
+        x = rng.integers(0, 100, n, dtype=np.uint32); y = rng.integers(1, 80, n, dtype=np.uint32)
+        v = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        ret = g.apply(op, x, y, v)
+        fin = g.apply(0, x, y)
+        k = x.astype(np.uint64) << 32 | y
+        uk, inv = np.unique(k, return_inverse=True)
+        hit = np.zeros(uk.size, dtype=bool)
+        np.logical_or.at(hit, inv, ret == fin)
+        assert hit.all()
+    g.close()
+
+
+def test_mem_field_tracks_the_tables(G):
+    """examples/smatrix_example.c:72 reads db->mem (src/smatrix.c:151-166 keeps it): non-zero from open on,
+    never shrinking while cells are only added; SURVEY A.1: the directory alone is 65536 x 16 B"""
+    m = G()
+    seen = [m.m.mem]
+    assert seen[0] >= 65536 * 16
+    rng = np.random.default_rng(1)
+    for n in (1, 10, 1000, 100000, 1000000):
+        x = rng.integers(0, 1 << 20, n, dtype=np.uint32); y = rng.integers(1, 1 << 20, n, dtype=np.uint32)
+        m.apply(2, x, y, np.ones(n, np.uint32))
+        seen.append(m.m.mem)
+    assert all(b >= a for a, b in zip(seen, seen[1:])) and seen[-1] > seen[0], seen
+    nnz = int(m.m.rowlen_batch(np.arange(1 << 20, dtype=np.uint32)).astype(np.uint64).sum())
+    assert seen[-1] >= 8 * nnz                                               # at least the cells themselves
+    m.incr(5, 5, 1)
+    assert m.m.mem >= seen[-1]
+    m.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_reference_benchmark_binary_through_the_shim(oracle_mod, tmp_path):
+    """The reference's UNCHANGED src/smatrix_benchmark.c, compiled on the build box against include/smatrix.h and
+    linked with lib/smatrix.o (oracle/Makefile -> oracle/_ref/smatrix_benchmark_hip), run HERE on the GPU: the shim
+    object dlopen()s smatrix.so, T pthreads hammer one handle through the scalar ABI (src/smatrix_benchmark.c:29-46,
+    :109-122), the file argument makes smatrix_close persist the result, and the oracle reads it back."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "smatrix_benchmark_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/smatrix_benchmark_hip not built (needs /root/reference on the build box)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from smatrix_benchmark import pattern
+    env = dict(os.environ, SMATRIX_HIP_LIB=os.path.join(ROOT, "libsmatrix_amd", "lib", "smatrix.so"))
+    for times, T in ((8, 4), (3, 1)):
+        path = str(tmp_path / ("stock_%d.smx" % T))
+        p = subprocess.run([exe, "incr", str(times), str(T), path], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+        assert "testing: %dk x incr @ %d threads:" % (times, T) in p.stdout and "ms" in p.stdout
+        p = subprocess.run([exe, "get", str(times), str(T), path], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]          # reopen + get through the shim
+        want = oracle_mod.Oracle()
+        for t in range(T):
+            x, y = pattern(t, times // T)
+            want.apply(2, x, y, np.ones_like(x))
+        got = oracle_mod.Oracle(path)
+        rows = want.list_rows().tolist()
+        assert sorted(got.list_rows().tolist()) == sorted(rows)
+        for r in rows:
+            assert got.row_info(r) == want.row_info(r)
+            a, b = got.getrow(r), want.getrow(r)
+            assert sorted(map(tuple, a.tolist())) == sorted(map(tuple, b.tolist()))
+        got.close(); want.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+def _cf_build_device(m, rows, torch, chunk_rows=1 << 17):
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = Stream("cf", SEED, CF_COLS, float(CF_PER_ROW), 1)
+    n_max = chunk_rows * CF_PER_ROW
+    x = torch.empty(n_max, dtype=torch.int32, device=dev); y = torch.empty_like(x)
+    ones = torch.ones_like(x); out = torch.empty_like(x)
+    for r0 in range(0, rows, chunk_rows):
+        n = (min(rows, r0 + chunk_rows) - r0) * CF_PER_ROW
+        gen.fill_device(r0 * CF_PER_ROW, n, x.data_ptr(), y.data_ptr(), st)
+        m.apply_batch_dev(2, n, x.data_ptr(), y.data_ptr(), ones.data_ptr(), out.data_ptr(), st)
+    torch.cuda.synchronize()
+    return gen
+
+
+def _cf_row_checks(m, gen, oracle_mod, row_numbers):
+    """each CF row's ops are contiguous in the stream: rebuild single rows in the oracle and compare everything"""
+    for rn in row_numbers:
+        x, y = gen.fill(rn * CF_PER_ROW, CF_PER_ROW)
+        o = oracle_mod.Oracle()
+        o.apply(2, x, y, np.ones(CF_PER_ROW, np.uint32))
+        X = int(x[0])
+        assert (x == X).all()
+        assert m.row_info(X) == o.row_info(X), rn
+        a, b = np.asarray(m.row_slots(X)), np.asarray(o.row_slots(X))
+        sa = a[np.lexsort((a[:, 1], a[:, 0]))]; sb = b[np.lexsort((b[:, 1], b[:, 0]))]
+        assert (sa == sb).all(), rn
+        pairs = m.getrow_raw(X, (m.getRowLength(X) + 1) * 8)
+        ne = a[(a[:, 0] != 0) | (a[:, 1] != 0)]
+        assert (pairs == ne).all(), rn                                          # slot order
+        o.close()
+
+
+def test_config3_cf_shape_1m_rows_vs_oracle(G, oracle_mod):
+    """SURVEY.md 6 scale of config 3 (1 M rows x 115 ops, uniform columns over 13 M, scrambled ids): the whole
+    matrix against the oracle -- rowlen of EVERY row, getrow content of sampled rows, sum get over the stream"""
+    rows = 1000000
+    n = rows * CF_PER_ROW
+    gen = Stream("cf", SEED, CF_COLS, float(CF_PER_ROW), 1)
+    x, y = gen.fill(0, n)
+    g, o = G(), oracle_mod.Oracle()
+    chunk = 1 << 24
+    for a in range(0, n, chunk):
+        ones = np.ones(min(chunk, n - a), np.uint32)
+        g.apply(2, x[a:a + chunk], y[a:a + chunk], ones)
+        o.apply(2, x[a:a + chunk], y[a:a + chunk], ones)
+    xs = x[::CF_PER_ROW].copy()
+    assert g.stats()["rows"] == o.num_rows() == rows
+    lens_g = g.m.rowlen_batch(xs)
+    lens_o = np.array([o.rowlen(int(r)) for r in xs[::97]], dtype=np.uint32)
+    assert (lens_g[::97] == lens_o).all()
+    nnz = int(lens_g.astype(np.uint64).sum())
+    assert nnz == np.unique(x.astype(np.uint64) << 32 | y).size
+    assert g.sum_get(x[: 1 << 24], y[: 1 << 24]) == o.sum_get(x[: 1 << 24], y[: 1 << 24])
+    sel = np.random.default_rng(4).integers(0, rows, 400)
+    off, pairs, cnt = g.m.getrow_batch(xs[sel])
+    for i, r in enumerate(sel.tolist()):
+        mine = pairs[off[i]: off[i] + cnt[i]]
+        theirs = o.getrow(int(xs[r]))
+        assert cnt[i] == theirs.shape[0] == lens_g[r]
+        assert (mine[np.lexsort((mine[:, 1], mine[:, 0]))] == theirs[np.lexsort((theirs[:, 1], theirs[:, 0]))]).all()
+        assert g.row_info(int(xs[r])) == o.row_info(int(xs[r]))
+    g.close(); o.close(); gen.close()
+
+
+def _fmix32_np(ids):
+    h = ids.astype(np.uint32).copy()
+    h ^= h >> 16; h *= np.uint32(0x85ebca6b); h ^= h >> 13; h *= np.uint32(0xc2b2ae35); h ^= h >> 16
+    return h
+
+
+def _cf_scan(m, rows, torch):
+    """rowlen + getrow over ALL rows on the device -> (nnz, key checksum, value sum, max rowlen, min rowlen)"""
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    xs = torch.from_numpy(_fmix32_np(np.arange(1, rows + 1, dtype=np.uint32)).view(np.int32)).to(dev)
+    lens = torch.empty(rows, dtype=torch.int32, device=dev)
+    m.rowlen_batch_dev(rows, xs.data_ptr(), lens.data_ptr(), st)
+    off = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens.long() + 1, 0, out=off[1:])                 # caller idiom: rowlen, then a buffer (+1: quirk Q5)
+    total = int(off[-1].item())
+    ret = torch.zeros((total, 2), dtype=torch.int32, device=dev)
+    cnt = torch.empty(rows, dtype=torch.int32, device=dev)
+    m.getrow_batch_dev(rows, xs.data_ptr(), off.data_ptr(), ret.data_ptr(), cnt.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert bool((cnt == lens).all())
+    out = (int(lens.sum(dtype=torch.int64).item()), int(ret[:, 0].sum(dtype=torch.int64).item()),
+           int(ret[:, 1].sum(dtype=torch.int64).item()), int(lens.max().item()), int(lens.min().item()))
+    del ret
+    return out
+
+
+def _cf_full(rows, path, oracle_mod, torch):
+    from libsmatrix_amd import SparseMatrix
+    m = SparseMatrix(path)
+    gen = _cf_build_device(m, rows, torch)
+    assert m.stats()["rows"] == rows
+    nnz, ksum, vsum, lmax, lmin = _cf_scan(m, rows, torch)
+    # every op is +1, so the values sum to the op count; a repeated (row, column) draw merges two ops into one cell
+    assert vsum == rows * CF_PER_ROW and rows * CF_PER_ROW * 0.9995 <= nnz <= rows * CF_PER_ROW
+    assert lmax <= CF_PER_ROW and lmin >= CF_PER_ROW - 5
+    sample = np.random.default_rng(rows).integers(0, rows, 60).tolist() + [0, rows - 1]
+    _cf_row_checks(m, gen, oracle_mod, sample)
+    if path:
+        m.close()                                                             # persist (src/smatrix.c:113-133)
+        assert os.path.getsize(path) > 8 * nnz
+        m = SparseMatrix(path)                                                # bulk load (src/smatrix.c:576-596)
+        assert m.stats()["rows"] == rows
+        assert _cf_scan(m, rows, torch)[:3] == (nnz, ksum, vsum)
+        _cf_row_checks(m, gen, oracle_mod, sample[:20])
+        for rn in sample[:5]:                                                 # still writable after the reload
+            X = int(gen.fill(rn * CF_PER_ROW, 1)[0][0])
+            before = m.getRowLength(X)
+            m.incr(X, 0xFFFFFFF0, 1)
+            assert m.getRowLength(X) == before + 1
+        m.close()
+        os.remove(path)
+    else:
+        m.close()
+    gen.close()
+    return nnz
+
+
+def test_config3_and_5_full_scale_13m_rows(oracle_mod, tmp_path):
+    """BASELINE config 3 at full size on one GPU -- 13 M rows / 1.495 G nnz / 27 GB of row tables, built on the
+    device -- checked through size-independent properties (sum rowlen == pairs getrow returns, values sum to the
+    op count, every sampled row identical to the oracle's rebuild of that row), and config 5's persist / close /
+    reopen / verify of the same matrix in the reference's file format (where the scratch disk has room for the
+    27 GB file; else the file leg runs at 2 M rows)."""
+    import torch
+    full_file = shutil.disk_usage(str(tmp_path)).free > 40e9
+    nnz = _cf_full(13000000, str(tmp_path / "cf13m.smx") if full_file else None, oracle_mod, torch)
+    assert nnz == CF13M_NNZ, nnz                      # fixed by the generator (include/smx_stream.h, SMX_DIST_CF)
+    if not full_file:
+        _cf_full(2000000, str(tmp_path / "cf2m.smx"), oracle_mod, torch)

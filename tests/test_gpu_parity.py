@@ -161,16 +161,46 @@ def test_random_mixed_batches_vs_oracle(G, oracle_mod, seed, nx, ny, n):
         elif op == 1:
             assert (a == v).all() and (b == v).all()
         else:
-            # returns are "value after the op in some serialisation": the per-key multiset is NOT
-            # order independent for mixed increments, but the final value is
-            last = per_key_sorted(x, y, np.arange(n, dtype=np.uint32))
-            del last
+            # returns are "value after the op in some serialisation": the per-key multiset is NOT order
+            # independent for mixed increments, but in every serialisation the LAST op of a key returns the
+            # key's final value -- the oracle's get must be among the key's returns (and is the oracle's own last)
+            fin = o.apply(0, x, y)
+            k = x.astype(np.uint64) << 32 | y
+            uk, inv = np.unique(k, return_inverse=True)
+            for ret in (a, b):
+                hit = np.zeros(uk.size, dtype=bool)
+                np.logical_or.at(hit, inv, ret == fin)
+                assert hit.all(), (seed, rnd)
         assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), (seed, rnd)
     rows = o.list_rows().tolist()
     state_equal(g, o, rows[:400], exact_layout=False)
     lens_g = g.m.rowlen_batch(np.array(rows, dtype=np.uint32))
     lens_o = np.array([o.rowlen(r) for r in rows], dtype=np.uint32)
     assert (lens_g == lens_o).all()
+    g.close(); o.close()
+
+
+def test_new_rows_colliding_in_one_directory_slot(G, oracle_mod):
+    """row ids crafted so that fmix32(x) & 0xFFFF is ONE value (fmix32 is a public bijection) all want
+    the same first-empty slot of the 65536-slot directory; creating 600 of them in one batch must converge (it
+    needed one round per id and died at 200) and give the oracle's rows"""
+    ids = np.arange(1, 1 << 26, dtype=np.uint32)
+    h = ids.copy()
+    h ^= h >> 16; h *= np.uint32(0x85ebca6b); h ^= h >> 13; h *= np.uint32(0xc2b2ae35); h ^= h >> 16
+    crowd = ids[(h & 0xFFFF) == 0x1234][:600]
+    assert crowd.size == 600
+    g, o = G(), oracle_mod.Oracle()
+    x = np.repeat(crowd, 3); y = np.tile(np.array([1, 2, 17], np.uint32), crowd.size)
+    a, b = g.apply(2, x, y, np.ones_like(x)), o.apply(2, x, y, np.ones_like(x))
+    assert (a == b).all()
+    assert g.stats()["rows"] == 600 and g.stats()["rounds"] <= 12
+    assert (g.apply(0, x, y) == 1).all()
+    for r in crowd[::50].tolist():
+        assert g.row_info(r) == o.row_info(r)
+    # one op per call on a second crowd: the scalar path creates rows behind occupied slots too
+    for r in ids[(h & 0xFFFF) == 0x1235][:40].tolist():
+        assert g.incr(r, 5, 2) == o.incr(r, 5, 2)
+    assert g.stats()["rows"] == 640
     g.close(); o.close()
 
 

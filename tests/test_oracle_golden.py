@@ -132,6 +132,24 @@ def test_survey_a4_checksum(oracle_mod):
     m.close()
 
 
+def test_survey_a4_checksum_1e7(oracle_mod):
+    """SURVEY.md A.4 ([probe] on the reference, 10^7 scrambled Zipf ops): sum over the stream of get(x_i,y_i) =
+    52 480 898 544, 561 596 rows, 4 463 637 nnz, hottest row 159 472 -- the figures the GPU path is held to in
+    tests/test_gpu_configs.py::test_config2_reference_checksums_1e7.  Where oracle/_ref exists, the compiled
+    reference itself is run beside the oracle."""
+    gen = Stream("zipf", 12345, 1000000, 1.1, 1)
+    x, y = gen.fill(0, 10000000)
+    for make in [oracle_mod.Oracle] + ([oracle_mod.Reference] if oracle_mod.have_reference() else []):
+        m = make()
+        m.apply(oracle_mod.OP_INCR, x, y, np.ones(x.size, np.uint32))
+        assert m.sum_get(x, y) == 52480898544
+        assert m.num_rows() == 561596
+        lens = np.array([m.rowlen(int(r)) for r in m.list_rows()], dtype=np.uint64)
+        assert int(lens.sum()) == 4463637 and int(lens.max()) == 159472
+        m.close()
+    gen.close()
+
+
 def test_fileformat(oracle_mod, golden, tmp_path):
     """the oracle's writer/loader against the reference-written file's decoded description"""
     from oracle.gen_golden import decode_file

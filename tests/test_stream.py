@@ -6,6 +6,8 @@ import pytest
 from libsmatrix_amd import _lib
 from libsmatrix_amd.stream import Stream
 
+CF_200K_ROWS_NNZ = 22999896
+
 
 def splitmix_ref(seed, n):
     """SplitMix64 as specified in SURVEY.md Appendix B (sequential form)"""
@@ -56,11 +58,33 @@ def test_zipf_inverse_cdf_definition():
     assert abs((x == 1).mean() - cdf[0]) < 0.02            # P(rank 1) = 1/H ~ 0.13 for N = 1000
 
 
+def test_cf_shape_definition():
+    """SMX_DIST_CF (BASELINE config 3, SURVEY.md 8d): op i -> row fmix32(1 + i // per_row), column
+    fmix32(1 + draw_i % n_cols), ONE draw per op"""
+    lib = _lib.load()
+    g = Stream("cf", 12345, 13000000, 115.0, 1)
+    x, y = g.fill(0, 1000)
+    r = splitmix_ref(12345, 1000)
+    assert x.tolist() == [lib.smx_fmix32(1 + i // 115) for i in range(1000)]
+    assert y.tolist() == [lib.smx_fmix32(1 + r[i] % 13000000) for i in range(1000)]
+    x2, y2 = g.fill(115 * 7 + 3, 300)                     # random access by op index
+    x3, y3 = g.fill(0, 115 * 7 + 303)
+    assert (x2 == x3[-300:]).all() and (y2 == y3[-300:]).all()
+    # distinct (row, column) cells of the first 200 000 rows; the full 13 M-row stream holds 1 494 993 467 of its
+    # 1 495 000 000 ops as distinct cells (same count, run over all rows: tests/test_gpu_configs.py::CF13M_NNZ)
+    x, y = g.fill(0, 200000 * 115)
+    assert np.unique(x.astype(np.uint64) << 32 | y).size == CF_200K_ROWS_NNZ
+    gd = Stream("cf", 5, 1000, 3.0, 0)
+    xd, yd = gd.fill(0, 9)
+    assert xd.tolist() == [1, 1, 1, 2, 2, 2, 3, 3, 3] and yd.min() >= 1 and yd.max() <= 1000
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("dist,n_ids,scr", [("zipf", 1000000, 1), ("zipf", 5000, 0), ("uniform", 1 << 20, 1)])
+@pytest.mark.parametrize("dist,n_ids,scr", [("zipf", 1000000, 1), ("zipf", 5000, 0), ("uniform", 1 << 20, 1),
+                                            ("cf", 13000000, 1)])
 def test_device_generator_equals_host(dist, n_ids, scr):
     import torch
-    g = Stream(dist, 777, n_ids, 1.1, scr)
+    g = Stream(dist, 777, n_ids, 115.0 if dist == "cf" else 1.1, scr)
     first, n = 123456789, 300000
     hx, hy = g.fill(first, n)
     dx = torch.empty(n, dtype=torch.int32, device="cuda"); dy = torch.empty_like(dx)
