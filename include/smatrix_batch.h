@@ -92,6 +92,10 @@ typedef struct {
   uint64_t rows_grown;      /* row doublings */
   uint64_t dir_grown;       /* directory rebuilds */
   uint64_t rows_rebalanced; /* big rows whose insert quotas were re-partitioned */
+  uint64_t long_probe_rounds; /* rounds in which ops were handed to the wave-cooperative window probe (clustered ids) */
+  uint64_t scalar_cache_hits;    /* scalar-ABI calls answered from the host-side cell mirror (no device round trip) */
+  uint64_t scalar_cache_flushes; /* write-backs of mirrored values (one batched set each) */
+  uint64_t scalar_cache_flushed_cells;
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];

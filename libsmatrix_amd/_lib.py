@@ -15,7 +15,8 @@ class Stats(C.Structure):
     # include/smatrix_batch.h smatrix_stats_t
     _fields_ = [(n, C.c_uint64) for n in (
         "rows", "dir_slots", "arena_units", "arena_mapped", "arena_free_units", "batches", "rounds",
-        "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced")] + [
+        "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced", "long_probe_rounds", "scalar_cache_hits", "scalar_cache_flushes",
+        "scalar_cache_flushed_cells")] + [
         ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
 
 

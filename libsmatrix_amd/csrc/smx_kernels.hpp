@@ -82,6 +82,7 @@ __host__ __device__ inline void subs_init(SubCtr* sc, uint32_t room) {
 
 enum Op : int { OP_GET = 0, OP_SET = 1, OP_INCR = 2, OP_DECR = 3 };
 
+
 // device-side control block, one per matrix.  The first part is zeroed at the start of every round;
 // the persistent part is owned by the device between readbacks.
 constexpr uint32_t N_CLASSES = 28;     // row block size classes: 16 * 2^c cells, c = log2(size) - 4
@@ -96,7 +97,8 @@ struct Ctl {
   uint32_t n_chunks_new; // same over the new tables
   uint32_t n_rebal;      // big rows whose sub-counter quotas want re-partitioning
   uint32_t n_kind[4];    // growth tasks by kind (grow_kind): LDS by wave / workgroup / large workgroup, chunked
-  uint32_t pad0[3];
+  uint32_t n_long;       // the folding kernel deferred ops whose probe outran its budget (the lane-per-op kernel takes them)
+  uint32_t pad0[2];
   // ---- persistent ----
   uint32_t dir_used;     // rows in the directory
   uint32_t pad1;
@@ -219,22 +221,72 @@ __device__ inline uint32_t* sub_ticket_elsewhere(SubCtr* subs, uint32_t k0) {
   return sub_ticket(subs);                       // the endgame pool (see subs_init)
 }
 
-// The per-op body: returns the op's result (new value for writers); *deferred is set when a
-// structure change must happen first.
-template <int OP, bool PATIENT = false>
-__device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
-                                     uint32_t Y, uint32_t V, bool* deferred) {
-  uint32_t result = 0;
-  uint4 s;
-  DirSlot* d = dir_find(dir, dmask, X, &s);
-  if (!d || s.z == 0) {
-    *deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
-    return 0;
+// ---- long probe sequences: the wave-cooperative window probe ---------------------------------------------
+// Row tables keep the reference's identity hash (y % size, src/smatrix.c:366) because their bytes are the file format.
+// With DENSE ids that hash clusters: low ids fill a contiguous run and every id that wraps onto the run walks to its
+// end (displacements of 10^3..10^4).  One lane stepping cell by cell through such a run is a chain
+// of thousands of dependent loads while the other 63 lanes of its wave idle.  So a lane probes PROBE_BUDGET cells on
+// its own (scrambled ids never get that far: the longest sequence in the 100 M-cell config-2 tables is ~30) and then
+// hands the probe to its WAVE: 64 lanes look at 64 consecutive cells per load (one coalesced 512-byte window, four
+// windows in flight), two ballots find the first cell that ends the reference's probe -- key == Y or empty
+// (src/smatrix.c:369-377) -- in probe order.
+struct LongProbe {
+  bool need;
+  const uint64_t* cells;
+  uint32_t mask, pos;          // continue at `pos`
+};
+#ifndef SMX_PROBE_BUDGET
+#define SMX_PROBE_BUDGET 48
+#endif
+constexpr uint32_t PROBE_BUDGET = SMX_PROBE_BUDGET;
+constexpr uint32_t PROBE_NONE = 0xFFFFFFFFu;
+
+// Called by ALL lanes of a wave together (convergent).  Lanes with `need` get the first slot at/after `pos`
+// (cyclically, at most one full turn) whose key is Y or that is empty; PROBE_NONE if the table has neither.
+// The answer is a hint for tables that are being written (the caller re-examines the slot), exact for quiescent ones.
+__device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t mask, uint32_t Y, uint32_t pos) {
+  const uint32_t lane = __lane_id();
+  uint64_t todo = __ballot(need);
+  uint32_t result = PROBE_NONE;
+  while (todo) {
+    const int src = __ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const uint64_t* cb = reinterpret_cast<const uint64_t*>(
+        ((uint64_t)(uint32_t)__shfl((int)((uint64_t)cells >> 32), src) << 32) | (uint32_t)__shfl((int)(uint64_t)cells, src));
+    const uint32_t mb = (uint32_t)__shfl((int)mask, src), yb = (uint32_t)__shfl((int)Y, src), pb = (uint32_t)__shfl((int)pos, src);
+    uint32_t found = PROBE_NONE;
+    for (uint64_t done = 0; done <= mb && found == PROBE_NONE; done += 256) {          // wave-uniform
+      uint64_t c[4];
+      bool ok[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const uint64_t off = done + (uint32_t)w * 64u + lane;
+        ok[w] = off <= mb;
+        c[w] = ok[w] ? cb[(pb + (uint32_t)off) & mb] : ~0ull;
+      }
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const uint64_t m = __ballot(ok[w] && (cell_key(c[w]) == yb || c[w] == 0));
+        if (m && found == PROBE_NONE) found = (pb + (uint32_t)done + (uint32_t)w * 64u + (uint32_t)(__ffsll((unsigned long long)m) - 1)) & mb;
+      }
+    }
+    if ((int)lane == src) result = found;
   }
+  return result;
+}
+
+// The per-op body on a row that exists: returns the op's result (new value for writers); *deferred is set when a
+// structure change must happen first.  Probing starts at `pos` (Y & mask for a fresh op).
+//   MODE 0  the lane probes to the end on its own (scalar ABI kernel, CF kernel)
+//   MODE 1  after PROBE_BUDGET cells the probe is handed back in *lp (lane-per-op kernels: coop_probe, then re-enter
+//           at the slot it found)
+template <int OP, bool PATIENT = false, int MODE = 0>
+__device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
+                                     bool* deferred, LongProbe* lp) {
+  uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
   uint64_t* cells = row_cells(arena, s.z);
-  uint32_t pos = Y & mask;
   if (OP == OP_GET) {
     // src/smatrix.c:369-377 then :299: hit iff the probed slot's key == y
     for (uint32_t step = 0; step <= mask; step++) {
@@ -242,6 +294,7 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
       if (cell_key(c) == Y) { result = cell_val(c); break; }
       if (c == 0) break;
       pos = (pos + 1) & mask;
+      if (MODE && step >= PROBE_BUDGET) { *lp = LongProbe{true, cells, mask, pos}; return 0; }
     }
   } else if (Y != 0) {
     uint64_t c = cells[pos];
@@ -283,6 +336,7 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
       }
       if (++steps > mask) { *deferred = true; return 0; }  // no empty cell at all: let prep grow it
       pos = (pos + 1) & mask;
+      if (MODE && steps > PROBE_BUDGET) { *lp = LongProbe{true, cells, mask, pos}; return 0; }
       c = cells[pos];
     }
     uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
@@ -311,6 +365,22 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
   return result;
 }
 
+// directory lookup + the per-op body (MODE as in apply_row)
+template <int OP, bool PATIENT = false, int MODE = 0>
+__device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
+                                     uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr) {
+  uint4 s;
+  DirSlot* d = dir_find(dir, dmask, X, &s);
+  if (!d || s.z == 0) {
+    *deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
+    return 0;
+  }
+  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp);
+}
+
+#ifndef SMX_APPLY_SGPRS
+#define SMX_APPLY_SGPRS 80
+#endif
 template <int OP>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
@@ -321,14 +391,29 @@ __device__ __forceinline__ void apply_body(
   for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
-    uint32_t j = 0;
+    uint32_t j = 0, r = 0, Y = 0, V = 0;
     bool deferred = false;
+    LongProbe lp{false, nullptr, 0, 0};
+    uint4 s = {0, 0, 0, 0};
+    DirSlot* d = nullptr;
     if (live) {
       j = idx ? idx[t] : t;
       const size_t at = (size_t)j * st;
-      uint32_t r = apply_one<OP, true>(dir, dmask, arena, xs[at], ys[at], OP != OP_GET ? vs[at] : 0u, &deferred);
-      if (!deferred) out[j] = r;
+      Y = ys[at];
+      V = OP != OP_GET ? vs[at] : 0u;
+      d = dir_find(dir, dmask, xs[at], &s);
+      if (!d || s.z == 0) deferred = (OP != OP_GET);      // get on an absent row: 0, creates nothing (S1)
+      else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp);
     }
+    while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+      if (lp.need) {
+        lp.need = false;
+        if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; }   // neither the key nor an empty cell: prep grows the row
+        else r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
+      }
+    }
+    if (live && !deferred) out[j] = r;
     if (OP != OP_GET) {
       // one list reservation per WORKGROUP: every atomic instruction on this one word queues at the
       // memory side (~34 ns each), and a retry round has thousands of waves with a deferred op
@@ -349,8 +434,9 @@ __device__ __forceinline__ void apply_body(
   }
 }
 
+// (pinned to the 80-SGPR budget like k_apply_agg: the writers compiled to 97-100 SGPRs, over the residency cliff)
 template <int OP>
-__global__ __launch_bounds__(256) void k_apply(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS))) void k_apply(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
@@ -491,7 +577,11 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       if (!(have & (1u << q))) continue;
       bool deferred = false;
       if (!(fast & (1u << q))) {
-        uint32_t res = apply_one<OP, SMX_AGG_PATIENT>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred);
+        // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
+        // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
+        LongProbe lp{false, nullptr, 0, 0};
+        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp);
+        if (lp.need) { deferred = true; ctl->n_long = 1; }
         old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
       }
       l_sum[hh[q]] = old[q];                                  // the cell's value before the tile
@@ -505,7 +595,9 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
   for (uint32_t k = 0; k < AGG_OPT; k++) {
     bool deferred = false;
     if (slot[k] == ~0u - 1) {
-      uint32_t r = apply_one<OP>(dir, dmask, arena, xs[(size_t)j[k] * ST], ys[(size_t)j[k] * ST], V[k], &deferred);
+      LongProbe lp{false, nullptr, 0, 0};
+      uint32_t r = apply_one<OP, false, 1>(dir, dmask, arena, xs[(size_t)j[k] * ST], ys[(size_t)j[k] * ST], V[k], &deferred, &lp);
+      if (lp.need) { deferred = true; ctl->n_long = 1; }
       if (!deferred) out[j[k]] = r;
     } else if (slot[k] != ~0u) {
       deferred = reinterpret_cast<uint32_t*>(&l_key[slot[k]])[0] != 0;
@@ -655,11 +747,12 @@ __device__ __forceinline__ void prep_body(
             const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull, (unsigned long long)want);
             if (prev == 0) { won = true; break; }
             if ((uint32_t)(prev >> 32) == X) break;         // another workgroup created this very row meanwhile
+            uint64_t cur;                                  // (ONE load per slot: it may be claimed between two looks)
             do {
               hh = (hh + 1) & dmask;
-            } while (ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh])) != 0 &&
-                     (uint32_t)(ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh])) >> 32) != X);
-            if (ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh])) != 0) break;   // it holds X
+              cur = ld_relaxed(reinterpret_cast<uint64_t*>(&dir[hh]));
+            } while (cur != 0 && (uint32_t)(cur >> 32) != X);
+            if (cur != 0) break;                           // it holds X
           }
           if (won) rank2 = atomicAdd(&l_cnt[1], 1u);
         } else {
@@ -699,6 +792,7 @@ __device__ __forceinline__ void prep_body(
     //    is this op's key absent?
     bool absent = false;
     uint32_t base = 0, lg = 0;
+    LongProbe lp{false, nullptr, 0, 0};
     if (live && !missing && Y != 0) {
       base = dir[h].base;          // plain: 0 only for a row created in this very launch
       if (base != 0) {
@@ -712,7 +806,15 @@ __device__ __forceinline__ void prep_body(
           if (cell_key(c) == Y) { absent = false; break; }
           if (c == 0) break;
           pos = (pos + 1) & mask;
+          if (step >= PROBE_BUDGET) { lp = LongProbe{true, cells, mask, pos}; break; }
         }
+      }
+    }
+    while (__any(lp.need)) {                        // long sequences (dense ids): the wave finishes them (coop_probe)
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+      if (lp.need) {
+        lp.need = false;
+        absent = p == PROBE_NONE || cell_key(lp.cells[p]) != Y;     // the table is quiescent here: the answer is final
       }
     }
     // D. once per row with an absent key: grow it iff it stands at the reference's threshold
@@ -1180,12 +1282,13 @@ __global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uin
 __global__ __launch_bounds__(256) void k_set_locate(DirSlot* dir, uint32_t dmask, uint8_t* arena,
                                                     uint32_t n, const uint32_t* __restrict__ xs,
                                                     const uint32_t* __restrict__ ys, uint64_t* cellp, uint32_t st) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = j < n;
   uint64_t where = ~0ull;
-  const uint32_t Y = ys[(size_t)j * st];
-  uint4 s;
-  DirSlot* d = Y ? dir_find(dir, dmask, xs[(size_t)j * st], &s) : nullptr;
+  const uint32_t Y = live ? ys[(size_t)j * st] : 0u;
+  uint4 s = {0, 0, 0, 0};
+  DirSlot* d = live && Y ? dir_find(dir, dmask, xs[(size_t)j * st], &s) : nullptr;
+  LongProbe lp{false, nullptr, 0, 0};
   if (d && s.z) {
     const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
     const uint64_t* cells = row_cells(arena, s.z);
@@ -1195,9 +1298,17 @@ __global__ __launch_bounds__(256) void k_set_locate(DirSlot* dir, uint32_t dmask
       if (cell_key(c) == Y) { where = (((uint64_t)s.z) << 4) + pos; break; }
       if (c == 0) break;
       pos = (pos + 1) & mask;
+      if (step >= PROBE_BUDGET) { lp = LongProbe{true, cells, mask, pos}; break; }
     }
   }
-  cellp[j] = where;
+  while (__any(lp.need)) {
+    const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+    if (lp.need) {
+      lp.need = false;
+      if (p != PROBE_NONE && cell_key(lp.cells[p]) == Y) where = (((uint64_t)s.z) << 4) + p;
+    }
+  }
+  if (live) cellp[j] = where;
 }
 __global__ __launch_bounds__(256) void k_set_clear(uint32_t n, const uint64_t* cellp, uint8_t* arena) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -192,10 +192,108 @@ struct DevBuf {
   }
 };
 
+constexpr size_t SCALAR_ROW_PAIRS_ALLOC = 8192 + 8;       // pinned pair buffer of the scalar getrow (+ slack for S4's overrun)
+
 struct ScalarReq {
   int op;
   uint32_t x, y, v, result;
   bool done;
+};
+
+// ---- host-side write-back cell cache of the scalar ABI --------------------------------------------------
+// The reference's callers issue ONE op per call (JNI, Ruby, src/smatrix_benchmark.c:29-65) and mostly return to
+// the same cells; a device round trip per call is ~15-20 us, ~360x the reference on its own benchmark.  Cells
+// the device is KNOWN to hold (a scalar call created or read them) are therefore mirrored here: get/set/incr/decr
+// on such a cell is host arithmetic on the mirrored value (exactly the reference's: :230/:241/:252, wrapping
+// uint32) and only marks the entry dirty; dirty values go back in one batched set before anything else can look
+// at the tables (batch calls, getrow, row dumps, close).
+//  * only value words are deferred -- a cell that is not known to exist takes the device path AT ONCE, so the
+//    order of insertions, and with it every table's byte layout, stays that of the call sequence;
+//  * y == 0 never enters (quirk Q1-Q3 cells change meaning with their value), and a y == 0 WRITE drops the whole
+//    cache: it can turn a (0,v) cell into an empty one and cut probe chains (the reference then no longer finds
+//    keys behind the cut, and neither may a cached entry);
+//  * batch writes drop it as well (they may touch mirrored cells).
+struct CellCache {
+  static constexpr unsigned SHARDS = 64;
+  struct Ent { uint32_t x, y, val, state; };          // state: 0 empty, 1 clean, 2 dirty
+  struct Shard {
+    std::mutex mu;
+    std::vector<Ent> tab;                              // open addressing, power of two
+    size_t used = 0, dirty = 0;
+  };
+  Shard sh[SHARDS];
+  bool enabled = true;
+  size_t shard_cap = (size_t)1 << 16;                  // entries per shard before the shard is recycled (4 M cells in all)
+  std::atomic<uint64_t> hits{0}, flushes{0}, flushed_cells{0};
+
+  static uint64_t mix(uint32_t x, uint32_t y) {
+    uint64_t z = ((uint64_t)x << 32 | y) * 0x9e3779b97f4a7c15ULL;
+    z ^= z >> 29; z *= 0xbf58476d1ce4e5b9ULL; z ^= z >> 32;
+    return z;
+  }
+  static Ent* find(Shard& s, uint64_t h, uint32_t x, uint32_t y) {
+    if (s.tab.empty()) return nullptr;
+    const size_t msk = s.tab.size() - 1;
+    for (size_t i = (h >> 6) & msk;; i = (i + 1) & msk) {
+      Ent& e = s.tab[i];
+      if (!e.state) return nullptr;
+      if (e.x == x && e.y == y) return &e;
+    }
+  }
+  // the host arithmetic of one op on a mirrored cell; false = not mirrored
+  bool apply(int op, uint32_t x, uint32_t y, uint32_t v, uint32_t* res) {
+    if (!enabled || y == 0) return false;
+    const uint64_t h = mix(x, y);
+    Shard& s = sh[h & (SHARDS - 1)];
+    std::lock_guard<std::mutex> g(s.mu);
+    Ent* e = find(s, h, x, y);
+    if (!e) return false;
+    if (op != OP_GET) {
+      e->val = op == OP_SET ? v : op == OP_INCR ? e->val + v : e->val - v;
+      if (e->state != 2) { e->state = 2; s.dirty++; }
+    }
+    *res = e->val;
+    hits.fetch_add(1, std::memory_order_relaxed);
+    return true;
+  }
+  // the device holds `val` in cell (x,y): mirror it (clean).  Caller holds the matrix lock.
+  void put(uint32_t x, uint32_t y, uint32_t val) {
+    if (!enabled || y == 0) return;
+    const uint64_t h = mix(x, y);
+    Shard& s = sh[h & (SHARDS - 1)];
+    std::lock_guard<std::mutex> g(s.mu);
+    if (s.tab.empty()) s.tab.assign(1024, Ent{0, 0, 0, 0});
+    if (Ent* e = find(s, h, x, y)) { if (e->state == 1) e->val = val; return; }   // (a dirty entry is newer than the device)
+    if (s.used >= shard_cap && s.dirty == 0) { std::fill(s.tab.begin(), s.tab.end(), Ent{0, 0, 0, 0}); s.used = 0; }
+    if (s.used >= shard_cap) return;                                             // full of dirty cells: until the next flush
+    if ((s.used + 1) * 2 > s.tab.size()) {
+      std::vector<Ent> old(s.tab.size() * 2, Ent{0, 0, 0, 0});
+      old.swap(s.tab);
+      const size_t msk = s.tab.size() - 1;
+      for (const Ent& e : old)
+        if (e.state) {
+          size_t i = (mix(e.x, e.y) >> 6) & msk;
+          while (s.tab[i].state) i = (i + 1) & msk;
+          s.tab[i] = e;
+        }
+    }
+    const size_t msk = s.tab.size() - 1;
+    size_t i = (h >> 6) & msk;
+    while (s.tab[i].state) i = (i + 1) & msk;
+    s.tab[i] = Ent{x, y, val, 1};
+    s.used++;
+  }
+  // dirty cells -> out (marked clean); clear: forget everything afterwards.  Caller holds the matrix lock.
+  void drain(std::vector<uint32_t>& xs, std::vector<uint32_t>& ys, std::vector<uint32_t>& vs, bool clear) {
+    for (Shard& s : sh) {
+      std::lock_guard<std::mutex> g(s.mu);
+      if (s.dirty)
+        for (Ent& e : s.tab)
+          if (e.state == 2) { xs.push_back(e.x); ys.push_back(e.y); vs.push_back(e.val); e.state = 1; }
+      s.dirty = 0;
+      if (clear && s.used) { std::fill(s.tab.begin(), s.tab.end(), Ent{0, 0, 0, 0}); s.used = 0; }
+    }
+  }
 };
 
 struct Matrix {
@@ -245,6 +343,10 @@ struct Matrix {
 
   std::string fname;
   bool dirty = false;                   // file mode: something changed since the file was loaded / last written
+  CellCache cache;                      // scalar ABI: mirrored cells (see CellCache)
+  DevBuf<uint64_t> row_ret;             // scalar getrow: pooled device buffer for rows that outgrow the pinned one
+  uint32_t* h_row = nullptr;            // pinned: {count, spare, big[2], offsets[2] (u64)} + pairs written by the kernel itself
+  bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
 };
 
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
@@ -354,11 +456,11 @@ void launch_apply_op(Matrix* m, int op, hipStream_t s, uint32_t n, const uint32_
     case OP_GET:  launch_apply<OP_GET>(m, s, n, idx, x, y, v, out, defer); break;
     case OP_SET:  launch_apply<OP_SET>(m, s, n, idx, x, y, v, out, defer); break;
     case OP_INCR:
-      if (n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
+      if (!m->long_probes && n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
       else launch_apply<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
       break;
     case OP_DECR:
-      if (n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
+      if (!m->long_probes && n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
       else launch_apply<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
       break;
     default: smx_die("bad op code");
@@ -441,6 +543,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   const uint32_t* idx = nullptr;
   bool timed0 = m->profile;
   uint32_t stalled = 0, rows_before = m->dir_used;
+  m->long_probes = false;
   for (uint32_t round = 0;; round++) {
     // the loop ends when nothing is deferred; it is abandoned only when rounds stop making PROGRESS (a fixed cap
     // would turn a slow but legal batch -- many new rows contending for one directory slot -- into an abort)
@@ -478,7 +581,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = m->h_ctl->n_defer;
     if (nd == 0) break;
-    const bool progress = nd < cur_n || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
+    if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
+    const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
     stalled = progress ? 0 : stalled + 1;
     rows_before = m->dir_used;
@@ -536,6 +640,30 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
   refresh_public(self);
 }
 
+// Writes the scalar ABI's mirrored values back (one batched set of cells that all exist: no structure change) before
+// anything reads the tables; `drop` additionally forgets the mirror (before writes that may touch mirrored cells).
+// Caller holds m->mu.
+void cache_sync(Matrix* m, bool drop) {
+  if (!m->cache.enabled) return;
+  std::vector<uint32_t> xs, ys, vs;
+  m->cache.drain(xs, ys, vs, drop);
+  const size_t k = xs.size();
+  if (!k) return;
+  hipStream_t s = m->stream;
+  m->sx.need(k); m->sy.need(k); m->sv.need(k); m->so.need(k);
+  HIP_OK(hipMemcpyAsync(m->sx.p, xs.data(), k * 4, hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(m->sy.p, ys.data(), k * 4, hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(m->sv.p, vs.data(), k * 4, hipMemcpyHostToDevice, s));
+  const uint32_t keep = m->in_stride;
+  m->in_stride = 1;
+  const uint64_t batches = m->st.batches;
+  run_write(m, OP_SET, (uint32_t)k, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);   // synchronises (set resolves duplicates last)
+  m->st.batches = batches;                                                     // bookkeeping of the caller's batches only
+  m->in_stride = keep;
+  m->cache.flushes++;
+  m->cache.flushed_cells += k;
+}
+
 }  // namespace
 
 // ---- persistence (src/smatrix.c:30-72 file format) ---------------------------------
@@ -574,6 +702,8 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipHostMalloc(&m->h_ctl, sizeof(Ctl)));
   HIP_OK(hipMalloc(&m->d_small, 64));
   HIP_OK(hipHostMalloc(&m->h_small, 64));
+  HIP_OK(hipHostMalloc(&m->h_row, 32 + (size_t)SCALAR_ROW_PAIRS_ALLOC * 8));
+  if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
   HIP_OK(hipEventCreate(&m->ev0));
   HIP_OK(hipEventCreate(&m->ev1));
   m->dir_size = 65536;                               // SMATRIX_CMAP_INITIAL_SIZE, src/smatrix.h:24
@@ -613,6 +743,7 @@ void smatrix_close(smatrix_t* self) {
     set_device(m);
     {
       std::lock_guard<std::mutex> g(m->mu);
+      cache_sync(m, true);
       if (!m->fname.empty() && self->fd && m->dirty) {     // a matrix that was only read has nothing to persist
         if (m->io_threads > 1) file_store(self, m);
         else file_store_serial(self, m);
@@ -626,6 +757,8 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_ctl) (void)hipHostFree(m->h_ctl);
       if (m->d_small) (void)hipFree(m->d_small);
       if (m->h_small) (void)hipHostFree(m->h_small);
+      if (m->h_row) (void)hipHostFree(m->h_row);
+      m->row_ret.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
@@ -652,6 +785,7 @@ int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   apply_dev_locked(self, op, n, d_x, d_y, d_v, d_out, s);
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
@@ -665,6 +799,7 @@ int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* 
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   m->in_stride = width;
   apply_dev_locked(self, op, n, d_records, d_records + 1, d_records + 2, d_out, s);
@@ -679,6 +814,7 @@ int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, co
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, op != OP_GET);
   hipStream_t s = m->stream;
   m->sx.need(n); m->sy.need(n); m->so.need(n);
   HIP_OK(hipMemcpyAsync(m->sx.p, x, n * 4, hipMemcpyHostToDevice, s));
@@ -760,6 +896,7 @@ int smatrix_getrow_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_x,
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   launch_getrow(m, s, (uint32_t)n, d_x, d_offsets, reinterpret_cast<uint64_t*>(d_ret), d_counts);
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
@@ -772,10 +909,11 @@ int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uin
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
   hipStream_t s = m->stream;
   const uint64_t total = offsets[n];
   m->sx.need(n); m->so.need(n); m->soff.need(n + 1);
-  DevBuf<uint64_t> dret;
+  DevBuf<uint64_t>& dret = m->row_ret;                       // pooled: no hipMalloc/hipFree per call
   dret.need(std::max<uint64_t>(total, 1));
   HIP_OK(hipMemcpyAsync(m->sx.p, x, n * 4, hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(m->soff.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
@@ -784,7 +922,7 @@ int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uin
   HIP_OK(hipStreamSynchronize(s));
   // copy only what was written per row? rows are packed by the caller's offsets: one copy
   if (total) HIP_OK(hipMemcpy(ret, dret.p, total * 8, hipMemcpyDeviceToHost));
-  dret.release();
+  if (dret.cap > ((size_t)64 << 20)) dret.release();         // (a rare giant request does not pin HBM for good)
   return 0;
 }
 
@@ -796,6 +934,7 @@ int smatrix_cf_neighbors_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
   hipLaunchKernelGGL(k_cf_neighbors, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
@@ -833,12 +972,15 @@ int smatrix_cf_neighbors_batch(smatrix_t* self, size_t n, const uint32_t* items,
   return 0;
 }
 
-// ---- the reference's scalar entry points: one-op batches --------------------------
-// One scalar op with the matrix lock held.
+static void row_info_locked(Matrix* m, uint32_t x, uint32_t* four);
+
+// ---- the reference's scalar entry points ----------------------------------------------------------
+// One scalar op on the device, with the matrix lock held.
 static uint32_t scalar_one_locked(smatrix_t* self, Matrix* m, int op, uint32_t x, uint32_t y, uint32_t v) {
   hipStream_t s = m->stream;
+  if (op != OP_GET && y == 0) cache_sync(m, true);       // a y = 0 write can cut probe chains: nothing stays mirrored
   // fast path: one launch, result written by the kernel into pinned host memory, one sync.
-  // (set keeps its value write inside apply_one; a one-op batch has no duplicates to resolve)
+  // (set keeps its value write inside apply_row; a one-op batch has no duplicates to resolve)
   {
     volatile uint32_t* res = m->h_small + 8;
     const dim3 one(1);
@@ -852,6 +994,8 @@ static uint32_t scalar_one_locked(smatrix_t* self, Matrix* m, int op, uint32_t x
     HIP_OK(hipStreamSynchronize(s));
     if (!res[1]) {
       if (op != OP_GET) { m->st.batches++; m->dirty = true; }
+      // after a write the cell exists and holds res[0]; a get proves existence only through a non-zero value
+      if (op != OP_GET || res[0] != 0) m->cache.put(x, y, res[0]);
       return res[0];
     }
   }
@@ -860,17 +1004,23 @@ static uint32_t scalar_one_locked(smatrix_t* self, Matrix* m, int op, uint32_t x
   apply_dev_locked(self, op, 1, m->d_small, m->d_small + 1, m->d_small + 2, m->d_small + 3, s);
   HIP_OK(hipMemcpyAsync(m->h_small + 3, m->d_small + 3, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
+  if (op != OP_GET) m->cache.put(x, y, m->h_small[3]);
   return m->h_small[3];
 }
 
 // The reference's scalar calls are thread-safe and callers (JVM threads, src/smatrix_jni.c) issue them
-// concurrently.  A device round trip per call would serialise them at ~15 us each, so concurrent
-// callers are COMBINED: every caller queues its op; whoever finds no combiner active becomes it, takes
-// everything queued so far and runs it as one batch per op kind (any order among concurrent calls is
-// a legal serialisation; each thread's own calls stay ordered because a thread has one call in flight).
-// A lone caller pays nothing extra: a queue of one goes down the one-launch fast path.
+// concurrently.  Calls on mirrored cells never get here (CellCache).  For the others a device round trip per call
+// would serialise the threads at ~15 us each, so concurrent callers are COMBINED: every caller queues its op;
+// whoever finds no combiner active becomes it, takes everything queued so far and runs it as one batch per op kind
+// (any order among concurrent calls is a legal serialisation; each thread's own calls stay ordered because a thread
+// has one call in flight).  A lone caller pays nothing extra: a queue of one goes down the one-launch fast path.
 static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint32_t v) {
   Matrix* m = M(self);
+  uint32_t hit;
+  if (m->cache.apply(op, x, y, v, &hit)) {
+    if (op != OP_GET) m->dirty = true;
+    return hit;
+  }
   ScalarReq req{op, x, y, v, 0, false};
   std::unique_lock<std::mutex> ql(m->qmu);
   m->queue.push_back(&req);
@@ -880,7 +1030,7 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
   }
   // become the combiner
   m->combining = true;
-  std::vector<ScalarReq*> work;
+  std::vector<ScalarReq*> work, dev;
   while (!m->queue.empty()) {
     work.clear();
     work.swap(m->queue);
@@ -888,18 +1038,27 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
     {
       set_device(m);
       std::lock_guard<std::mutex> g(m->mu);
-      if (work.size() == 1) {
-        ScalarReq* r = work[0];
+      // a cell may have been mirrored while this request waited for the lock (another thread's device op on it):
+      // look again -- under the matrix lock mirrored-ness cannot change under us
+      dev.clear();
+      for (ScalarReq* r : work)
+        if (!m->cache.apply(r->op, r->x, r->y, r->v, &r->result)) dev.push_back(r);
+        else if (r->op != OP_GET) m->dirty = true;
+      if (dev.size() == 1) {
+        ScalarReq* r = dev[0];
         r->result = scalar_one_locked(self, m, r->op, r->x, r->y, r->v);
-      } else {
+      } else if (!dev.empty()) {
         hipStream_t s = m->stream;
+        bool y0_write = false;
+        for (ScalarReq* r : dev) y0_write |= r->op != OP_GET && r->y == 0;
+        cache_sync(m, y0_write);
         for (int kind = 0; kind < 4; kind++) {
           size_t k = 0;
-          for (ScalarReq* r : work) k += r->op == kind;
+          for (ScalarReq* r : dev) k += r->op == kind;
           if (!k) continue;
           std::vector<uint32_t> hx(k), hy(k), hv(k), ho(k);
           size_t i = 0;
-          for (ScalarReq* r : work)
+          for (ScalarReq* r : dev)
             if (r->op == kind) { hx[i] = r->x; hy[i] = r->y; hv[i] = r->v; i++; }
           m->sx.need(k); m->sy.need(k); m->sv.need(k); m->so.need(k);
           HIP_OK(hipMemcpyAsync(m->sx.p, hx.data(), k * 4, hipMemcpyHostToDevice, s));
@@ -909,8 +1068,20 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
           HIP_OK(hipMemcpyAsync(ho.data(), m->so.p, k * 4, hipMemcpyDeviceToHost, s));
           HIP_OK(hipStreamSynchronize(s));
           i = 0;
-          for (ScalarReq* r : work)
+          for (ScalarReq* r : dev)
             if (r->op == kind) r->result = ho[i++];
+        }
+        // cells written exactly once in this combined group now exist with a known value: mirror them
+        // (a cell named twice has two results of which only "some serialisation" is known -- left to the next call)
+        std::vector<uint64_t> keys;
+        keys.reserve(dev.size());
+        for (ScalarReq* r : dev) keys.push_back((uint64_t)r->x << 32 | r->y);
+        std::sort(keys.begin(), keys.end());
+        for (ScalarReq* r : dev) {
+          if (r->op == OP_GET) continue;
+          const uint64_t key = (uint64_t)r->x << 32 | r->y;
+          auto range = std::equal_range(keys.begin(), keys.end(), key);
+          if (range.second - range.first == 1) m->cache.put(r->x, r->y, r->result);
         }
       }
     }
@@ -928,6 +1099,7 @@ uint32_t smatrix_set(smatrix_t* self, uint32_t x, uint32_t y, uint32_t value) { 
 uint32_t smatrix_incr(smatrix_t* self, uint32_t x, uint32_t y, uint32_t value) { return scalar_op(self, OP_INCR, x, y, value); }
 uint32_t smatrix_decr(smatrix_t* self, uint32_t x, uint32_t y, uint32_t value) { return scalar_op(self, OP_DECR, x, y, value); }
 
+// src/smatrix.c:212-223.  rmap->used does not depend on mirrored VALUES, so nothing is written back first.
 uint32_t smatrix_rowlen(smatrix_t* self, uint32_t x) {
   uint32_t out = 0;
   smatrix_rowlen_batch(self, 1, &x, &out);
@@ -935,19 +1107,54 @@ uint32_t smatrix_rowlen(smatrix_t* self, uint32_t x) {
 }
 
 // src/smatrix.c:189-210: ret_len counts BYTES and the loop stops once pairs*8 >= ret_len,
-// so a non-empty row always yields at least one pair (S4)
+// so a non-empty row always yields at least one pair (S4).
+// ONE device round trip for rows of up to SCALAR_ROW_PAIRS pairs (what the bindings ask for, smatrix_jni.c:130-139):
+// the row kernel writes its count and the pairs straight into pinned host memory.
+static constexpr uint32_t SCALAR_ROW_PAIRS = 8192;      // 64 KB pinned
 uint32_t smatrix_getrow(smatrix_t* self, uint32_t x, uint32_t* ret, size_t ret_len) {
   uint64_t cap = (ret_len + 7) / 8;
   if (cap == 0) cap = 1;
-  uint64_t offs[2] = {0, cap};
-  uint32_t size = 0, used = 0;
-  if (!smatrix_row_info(self, x, &size, &used)) return 0;
-  if (cap > size) { cap = size; offs[1] = cap; }
-  if (cap == 0) return 0;
-  std::vector<uint32_t> tmp(cap * 2);
-  uint32_t count = 0;
-  smatrix_getrow_batch(self, 1, &x, offs, tmp.data(), &count);
-  memcpy(ret, tmp.data(), (size_t)count * 8);
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
+  hipStream_t s = m->stream;
+  // h_row: [0] count, [1] x, [2..3] big list {n, first}, [4..7] offsets {0, cap} as u64, then the pairs
+  uint32_t* h = m->h_row;
+  uint64_t* offs = reinterpret_cast<uint64_t*>(h + 4);
+  uint64_t* pairs = reinterpret_cast<uint64_t*>(h + 8);
+  const uint64_t want = std::min<uint64_t>(cap, 0xffffffffull);
+  if (want <= SCALAR_ROW_PAIRS) {
+    h[0] = 0; h[1] = x; h[2] = 0; h[3] = 0;
+    offs[0] = 0; offs[1] = want;
+    hipLaunchKernelGGL(k_getrow, dim3(1), dim3(64), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, 1u, h + 1,
+                       offs, pairs, h, h + 2);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(s));
+    if (h[2]) {                                           // a row of more than 8192 cells: the workgroup-per-row kernel
+      hipLaunchKernelGGL(k_getrow_big, dim3(1), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, h + 1, offs,
+                         pairs, h, h + 2);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipStreamSynchronize(s));
+    }
+    const uint32_t count = h[0];
+    memcpy(ret, pairs, (size_t)count * 8);
+    return count;
+  }
+  // a larger buffer: bounded by the row's size, through the pooled device buffer
+  uint32_t f[4];
+  row_info_locked(m, x, f);
+  if (!f[0]) return 0;
+  const uint64_t room = std::min<uint64_t>(want, f[1]);
+  if (room == 0) return 0;
+  h[0] = 0; h[1] = x; h[2] = 0; h[3] = 0;
+  offs[0] = 0; offs[1] = room;
+  m->row_ret.need(room);
+  launch_getrow(m, s, 1, h + 1, offs, m->row_ret.p, h);
+  HIP_OK(hipStreamSynchronize(s));
+  const uint32_t count = h[0];
+  if (count) HIP_OK(hipMemcpy(ret, m->row_ret.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+  if (m->row_ret.cap > ((size_t)64 << 20)) m->row_ret.release();
   return count;
 }
 
@@ -962,6 +1169,9 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   for (uint32_t c = 0; c < N_CLASSES; c++)
     if (m->free_cnt[c] > 0) m->st.arena_free_units += (uint64_t)m->free_cnt[c] * block_units(c + ROW_FIRST_LG);
   m->st.arena_mapped = m->arena.mapped;
+  m->st.scalar_cache_hits = m->cache.hits.load();
+  m->st.scalar_cache_flushes = m->cache.flushes.load();
+  m->st.scalar_cache_flushed_cells = m->cache.flushed_cells.load();
   *out = m->st;
 }
 
@@ -1002,6 +1212,7 @@ uint32_t smatrix_row_slots(smatrix_t* self, uint32_t x, uint32_t* kv, uint32_t c
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
   uint32_t f[4];
   row_info_locked(m, x, f);
   if (!f[0] || !f[3]) return 0;

@@ -193,7 +193,7 @@ def test_new_rows_colliding_in_one_directory_slot(G, oracle_mod):
     x = np.repeat(crowd, 3); y = np.tile(np.array([1, 2, 17], np.uint32), crowd.size)
     a, b = g.apply(2, x, y, np.ones_like(x)), o.apply(2, x, y, np.ones_like(x))
     assert (a == b).all()
-    assert g.stats()["rows"] == 600 and g.stats()["rounds"] <= 12
+    assert g.stats()["rows"] == 600 and g.stats()["rounds"] <= 4      # create, insert (+ slack), not one round per id
     assert (g.apply(0, x, y) == 1).all()
     for r in crowd[::50].tolist():
         assert g.row_info(r) == o.row_info(r)
@@ -305,6 +305,43 @@ def test_dense_ids_long_probe_chains(G, oracle_mod):
     rows = o.list_rows()
     assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
     g.close(); o.close()
+
+
+def test_dense_ids_cooperative_probe_all_ops(G, oracle_mod):
+    """Clustered tables (dense Zipf ids: the reference's identity hash piles ids that wrap onto the dense low run
+    behind it, SURVEY.md A.4: displacement up to 12 674) drive every kernel into the wave-cooperative window probe
+    (coop_probe): get, incr/decr through the folding kernel (ops set aside -> lane-per-op retry), set with
+    duplicate resolution (k_set_locate), prep's absent-key test at the growth threshold.  Same answers, same row
+    sizes/rowlens as the oracle; batches and single ops mixed."""
+    gen = Stream("zipf", 4242, 300000, 1.1, 0)
+    g, o = G(), oracle_mod.Oracle()
+    n = 600000
+    x, y = gen.fill(0, n)
+    x = (x % 40).astype(np.uint32)                      # few rows -> large clustered tables (2^13 .. 2^17 cells)
+    rng = np.random.default_rng(9)
+    for rnd, op in enumerate((2, 3, 1, 2, 0)):
+        a0, a1 = rnd * 100000, rnd * 100000 + 200000
+        xs, ys = x[a0:a1], y[a0:a1]
+        v = ((xs + ys) % 3 + 1).astype(np.uint32)
+        if op == 1:                                     # set: one value per key so that the result is order-free
+            v = (ys % 7).astype(np.uint32)
+        a, b = g.apply(op, xs, ys, v), o.apply(op, xs, ys, v)
+        if op == 0:
+            assert (a == b).all()
+        assert (g.apply(0, xs, ys) == o.apply(0, xs, ys)).all(), rnd
+    assert g.stats()["long_probe_rounds"] > 0           # the folding kernel did hand ops over
+    # ids far outside the table wrap onto the dense run: absent keys (get must walk the whole run), then inserts
+    far = (np.arange(1, 5001, dtype=np.uint32) * 131072 + rng.integers(1, 200, 5000).astype(np.uint32))
+    xr = rng.integers(0, 40, 5000, dtype=np.uint32)
+    assert (g.apply(0, xr, far) == o.apply(0, xr, far)).all()
+    for k in range(40):                                 # scalar ABI on clustered rows
+        assert g.incr(int(xr[k]), int(far[k]), 2) == o.incr(int(xr[k]), int(far[k]), 2)
+    a, b = g.apply(2, xr, far, np.ones(5000, np.uint32)), o.apply(2, xr, far, np.ones(5000, np.uint32))
+    assert (g.apply(0, xr, far) == o.apply(0, xr, far)).all()
+    rows = o.list_rows()
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    state_equal(g, o, rows.tolist()[:12], exact_layout=False)
+    g.close(); o.close(); gen.close()
 
 
 def test_threads_on_one_handle(G):

@@ -39,7 +39,7 @@ def main():
     times = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     only_t = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     fname = sys.argv[4] if len(sys.argv) > 4 else None
-    scalar_cap = int(os.environ.get("SMX_BENCH_SCALAR_OPS", "20000"))
+    scalar_cap = int(os.environ.get("SMX_BENCH_SCALAR_OPS", "0")) or (1 << 62)     # 0 = the full op count
     Ts = [only_t] if only_t else [1, 2, 4, 8, 16, 32]
     import libsmatrix_amd
     from libsmatrix_amd import SparseMatrix
@@ -62,14 +62,14 @@ def main():
                     (m.incr_batch(x, y, np.ones_like(x)) if op == "incr" else m.get_batch(x, y))
                     cells.append("%.1fms" % ((time.perf_counter() - t0) * 1e3))
                 else:
-                    per = max(scalar_cap // T, 1)          # bounded sample, scaled to the full op count
+                    per = min(max(scalar_cap // T, 1), user1 * 1012)   # optionally a bounded sample, scaled to the full op count
                     def fn(t):
                         x, y = pattern(t, 1)
                         f = (lambda a, b: m.incr(a, b, 1)) if op == "incr" else m.get
                         for k in range(per):
                             f(int(x[k % x.size]), int(y[k % y.size]))
                     ms = measure(fn, T)
-                    cells.append("~%.0fms" % (ms * (user1 * 1012.0 / per)))
+                    cells.append(("%.1fms" if per == user1 * 1012 else "~%.0fms") % (ms * (user1 * 1012.0 / per)))
             print("%-11s" % name + "".join("%-11s" % c for c in cells))
             m.close()
         print()
