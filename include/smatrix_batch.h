@@ -96,6 +96,8 @@ typedef struct {
   uint64_t scalar_cache_hits;    /* scalar-ABI calls answered from the host-side cell mirror (no device round trip) */
   uint64_t scalar_cache_flushes; /* write-backs of mirrored values (one batched set each) */
   uint64_t scalar_cache_flushed_cells;
+  uint64_t file_flushes;         /* file mode: write-outs of dirty rows (smatrix_flush, SMATRIX_FLUSH_EVERY, close) */
+  uint64_t file_rows_written;    /* rows those write-outs wrote (a clean row is never rewritten) */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];
@@ -104,6 +106,13 @@ typedef struct {
 } smatrix_stats_t;
 
 void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
+/* File mode: writes every row that changed since the last flush to the backing file NOW (dirty rows only -- in
+ * place when the row's table still has its on-disk size, else as a fresh block whose CMAP entry is re-pointed, the
+ * reference's own scheme, src/smatrix.c:418-496); row blocks first, then the entries that publish them.  smatrix_close
+ * does the same one last time.  The reference has no such call: its IO thread flushes continuously (:929-960) and
+ * close is its only barrier (:113-133).  SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch, SMATRIX_FSYNC=1
+ * adds fsync() after the row blocks and after the entries.  Memory mode: no-op.  Returns 0. */
+int smatrix_flush(smatrix_t* self);
 /* on: time every round-0 op kernel with HIP events on its stream (adds one sync per
  * batch); resets the kernel_* accumulators.  Also enabled by SMATRIX_PROFILE=1. */
 void smatrix_profile(smatrix_t* self, int on);

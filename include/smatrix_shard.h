@@ -62,6 +62,43 @@ int smatrix_unpack_dev(size_t n, uint32_t width, const uint32_t* d_packed, uint3
 int smatrix_gather_dev(size_t n, const uint32_t* d_src, const uint32_t* d_perm, uint32_t* d_out,
                        void* hip_stream);
 
+/* ---- the router: the multi-GPU path behind the C boundary -------------------------------------------------
+ * One process per GPU.  Every rank opens its shard with the SAME 128-byte id (made once by
+ * smatrix_shard_unique_id on rank 0 and handed to the others by whatever launched the processes -- MPI, a file,
+ * torch.distributed's store); the library then talks RCCL itself: per batch one grouped ncclSend/ncclRecv exchange
+ * of the per-peer counts, one of the packed {x,y[,v]} records, one of the results (an alltoallv over xGMI, each peer
+ * pair on its own link).  RCCL is loaded at run time (librccl.so.1, or the copy the process already holds); with
+ * nranks == 1 it is not needed at all.
+ * All calls on a shard handle are COLLECTIVE: every rank calls them in the same order, each with its own n (0 is
+ * fine).  d_* are device pointers on this rank's GPU; work is enqueued on hip_stream (NULL = the legacy default
+ * stream, then the call also waits for it).  Results are in the caller's op order.  Semantics of one batch: the
+ * batch contract of smatrix_batch.h over the UNION of all ranks' ops (ops of different ranks on one key are
+ * "concurrent callers"). */
+typedef struct smatrix_shard smatrix_shard_t;
+#define SMATRIX_SHARD_ID_BYTES 128
+
+int smatrix_shard_unique_id(void* id128);                       /* 0 on success (needs RCCL) */
+/* fname: this rank's backing file or NULL; returns NULL on failure (no device, RCCL missing, bad rank) */
+smatrix_shard_t* smatrix_shard_open(const char* fname, int rank, int nranks, const void* id128);
+void smatrix_shard_close(smatrix_shard_t* sh);                  /* collective; closes (and persists) the local shard */
+/* this rank's shard as an ordinary handle: rowlen/getrow scans of the rows it owns, stats, smatrix_flush */
+smatrix_t* smatrix_shard_local(smatrix_shard_t* sh);
+int smatrix_shard_rank(smatrix_shard_t* sh);
+int smatrix_shard_nranks(smatrix_shard_t* sh);
+uint64_t smatrix_shard_ops_applied(smatrix_shard_t* sh);        /* ops this rank's shard has applied (load balance) */
+
+/* optional skew-aware placement (see PLACEMENT above), identical on every rank, before the first batch:
+ * cuts: nranks-1 host words or NULL; place_pairs: place_slots x {x, owner+1} host words (open addressing as above) */
+int smatrix_shard_set_placement(smatrix_shard_t* sh, const uint32_t* cuts, const uint32_t* place_pairs, uint32_t place_slots);
+
+/* op = SMATRIX_OP_* (smatrix_batch.h); d_v may be NULL for get */
+int smatrix_shard_apply_dev(smatrix_shard_t* sh, int op, size_t n, const uint32_t* d_x, const uint32_t* d_y,
+                            const uint32_t* d_v, uint32_t* d_out, void* hip_stream);
+/* a write batch and a get on the SAME keys right behind it (the "mixed incr+get" step of the benchmark,
+ * src/smatrix_benchmark.c:226-230) with ONE partition and ONE record exchange instead of two */
+int smatrix_shard_apply_then_get_dev(smatrix_shard_t* sh, int op, size_t n, const uint32_t* d_x, const uint32_t* d_y,
+                                     const uint32_t* d_v, uint32_t* d_out, uint32_t* d_out_get, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

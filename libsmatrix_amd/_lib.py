@@ -16,7 +16,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rows", "dir_slots", "arena_units", "arena_mapped", "arena_free_units", "batches", "rounds",
         "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced", "long_probe_rounds", "scalar_cache_hits", "scalar_cache_flushes",
-        "scalar_cache_flushed_cells")] + [
+        "scalar_cache_flushed_cells", "file_flushes", "file_rows_written")] + [
         ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
 
 
@@ -67,6 +67,7 @@ def load():
         "smatrix_cf_neighbors_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V, V, V, V]),
         "smatrix_stats": (None, [H, C.POINTER(Stats)]),
         "smatrix_profile": (None, [H, C.c_int]),
+        "smatrix_flush": (C.c_int, [H]),
         "smatrix_row_info": (C.c_int, [H, C.c_uint32, u32p, u32p]),
         "smatrix_row_slots": (C.c_uint32, [H, C.c_uint32, u32p, C.c_uint32]),
         "smatrix_device_available": (C.c_int, []),
@@ -79,6 +80,16 @@ def load():
         "smatrix_displaced_rows": (C.c_size_t, [V, C.c_uint32, C.c_uint32, V, C.c_size_t]),
         "smatrix_unpack_dev": (C.c_int, [C.c_size_t, C.c_uint32, V, V, V, V, V]),
         "smatrix_gather_dev": (C.c_int, [C.c_size_t, V, V, V, V]),
+        "smatrix_shard_unique_id": (C.c_int, [V]),
+        "smatrix_shard_open": (V, [C.c_char_p, C.c_int, C.c_int, V]),
+        "smatrix_shard_close": (None, [V]),
+        "smatrix_shard_local": (H, [V]),
+        "smatrix_shard_rank": (C.c_int, [V]),
+        "smatrix_shard_nranks": (C.c_int, [V]),
+        "smatrix_shard_ops_applied": (C.c_uint64, [V]),
+        "smatrix_shard_set_placement": (C.c_int, [V, V, V, C.c_uint32]),
+        "smatrix_shard_apply_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, V, V, V, V]),
+        "smatrix_shard_apply_then_get_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, V, V, V, V, V]),
         # include/smx_probe.h
         "smx_probe_random_dev": (C.c_int, [V, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, V, V]),
         # include/smx_stream.h

@@ -37,6 +37,11 @@ static_assert(sizeof(DirSlot) == 16, "DirSlot must be 16 bytes");
 
 constexpr uint32_t META_USED = 1u;
 constexpr uint32_t META_GROW = 1u << 16;
+// the row changed since it was last written to the backing file (the reference's SMATRIX_RMAP_FLAG_DIRTY,
+// src/smatrix.h:17, set by smatrix_rmap_sync_defer :418-425): set by every writer, by row creation and by growth;
+// collected and cleared by the flush (k_dirty_collect).  Writers store it only when their snapshot of the slot does
+// not show it yet, so a row pays one extra 4-byte store per flush interval (in memory mode: once).
+constexpr uint32_t META_DIRTY = 1u << 18;
 constexpr uint32_t META_LG_SHIFT = 8;
 constexpr uint32_t ROW_FIRST_LG = 4;  // SMATRIX_RMAP_INITIAL_SIZE 16, src/smatrix.h:21
 constexpr uint32_t UNIT_BYTES = 128;  // 16 cells
@@ -78,6 +83,7 @@ __host__ __device__ inline void subs_init(SubCtr* sc, uint32_t room) {
     sc[k].cnt = 0;
     sc[k].quota = room < SUBS_ENDGAME ? (k == 0 ? room : 0u) : room / SUBS + (k < room % SUBS ? 1u : 0u);
   }
+  sc[0].pad[0] = 0;                                // "every share is used up" (sub_ticket_anywhere)
 }
 
 enum Op : int { OP_GET = 0, OP_SET = 1, OP_INCR = 2, OP_DECR = 3 };
@@ -218,7 +224,17 @@ __device__ inline uint32_t* sub_ticket(SubCtr* sc) {
 __device__ inline uint32_t* sub_ticket_elsewhere(SubCtr* subs, uint32_t k0) {
   for (uint32_t a = 1; a < 4; a++)
     if (uint32_t* t = sub_ticket(subs + ((k0 + a * (SUBS / 4u)) & (SUBS - 1u)))) return t;
-  return sub_ticket(subs);                       // the endgame pool (see subs_init)
+  if (uint32_t* t = sub_ticket(subs)) return t;  // the endgame pool (see subs_init)
+  // Still nothing: look at EVERY share before giving up.  An op of a big row is then deferred only when the row
+  // really stands at the reference's threshold, so prep grows it at once -- a row that was merely unevenly drained
+  // used to cost a re-partition round, then the fill round, then the growth round (three rounds per batch for the
+  // ~10 big rows that cross their threshold; now two).  The scan is 64 cached 8-byte loads; once it has come up
+  // empty the row is marked so that the ops behind it do not repeat it.
+  if (__hip_atomic_load(&subs[0].pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return nullptr;
+  for (uint32_t a = 1; a < SUBS; a++)
+    if (uint32_t* t = sub_ticket(subs + ((k0 + a) & (SUBS - 1u)))) return t;
+  __hip_atomic_store(&subs[0].pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return nullptr;
 }
 
 // ---- long probe sequences: the wave-cooperative window probe ---------------------------------------------
@@ -287,6 +303,9 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
   uint64_t* cells = row_cells(arena, s.z);
+  // (meta does not change while op kernels run -- structure changes have their own launches -- so every lane that
+  //  marks the row stores the same word)
+  if (OP != OP_GET && !(s.x & META_DIRTY)) d->meta = s.x | META_DIRTY;
   if (OP == OP_GET) {
     // src/smatrix.c:369-377 then :299: hit iff the probed slot's key == y
     for (uint32_t step = 0; step <= mask; step++) {
@@ -534,6 +553,13 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
   // memory round trips of one key overlap with those of the others; anything else (collision,
   // insert, missing row) falls back to the generic per-op body.
   const uint32_t nd = l_n;
+#ifdef SMX_AGG_DBG
+  // measurement builds only (tools/probe/agg_phases.sh): once the host has set ctl->pad1, part of phase 2 is left out
+  // so that its share of the kernel's time can be read off (the tables are wrong afterwards: timing runs only)
+  const uint32_t dbg = aload(&ctl->pad1) ? SMX_AGG_DBG : 0;
+#else
+  constexpr uint32_t dbg = 0;
+#endif
   {
     uint32_t hh[AGG_OPT], tot[AGG_OPT], old[AGG_OPT];
     uint64_t kk[AGG_OPT];
@@ -549,8 +575,17 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         hh[q] = l_list[i];
         kk[q] = l_key[hh[q]];
         tot[q] = l_sum[hh[q]];
-        ds[q] = *reinterpret_cast<const uint4*>(&dir[fmix32((uint32_t)kk[q]) & dmask]);
+        if (dbg != 2) ds[q] = *reinterpret_cast<const uint4*>(&dir[fmix32((uint32_t)kk[q]) & dmask]);
       }
+    }
+    if (dbg == 2 || dbg == 3) {                  // 2: no global access at all in phase 2; 3: directory loads only
+#pragma unroll
+      for (uint32_t q = 0; q < AGG_OPT; q++) {
+        if (!(have & (1u << q))) continue;
+        l_sum[hh[q]] = dbg == 3 ? ds[q].w : 0u;
+        reinterpret_cast<uint32_t*>(&l_key[hh[q]])[0] = 0u;
+      }
+      have = 0;
     }
 #pragma unroll
     for (uint32_t q = 0; q < AGG_OPT; q++) {
@@ -567,7 +602,9 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       if (!(fast & (1u << q))) continue;
       if (cell_key(cc[q]) == (uint32_t)(kk[q] >> 32)) {
         uint32_t* vp = reinterpret_cast<uint32_t*>(cp[q]) + 1;
-        old[q] = OP == OP_INCR ? atomicAdd(vp, tot[q]) : atomicSub(vp, tot[q]);
+        if (dbg == 1) old[q] = cell_val(cc[q]);            // hits without their atomic
+        else old[q] = OP == OP_INCR ? atomicAdd(vp, tot[q]) : atomicSub(vp, tot[q]);
+        if (!(ds[q].x & META_DIRTY)) dir[fmix32((uint32_t)kk[q]) & dmask].meta = ds[q].x | META_DIRTY;
       } else {
         fast &= ~(1u << q);
       }
@@ -576,6 +613,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
     for (uint32_t q = 0; q < AGG_OPT; q++) {
       if (!(have & (1u << q))) continue;
       bool deferred = false;
+      if (dbg == 4 && !(fast & (1u << q))) { old[q] = 0; fast |= 1u << q; }     // 4: the slow path (inserts, collisions) left out
       if (!(fast & (1u << q))) {
         // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
@@ -742,7 +780,7 @@ __device__ __forceinline__ void prep_body(
       uint32_t rank2 = 0;
       if (at_empty) {
         if (l_cnt[3] && (uint64_t)l_cnt[2] + rank < dir_limit) {
-          const uint64_t want = (uint64_t)(META_USED | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+          const uint64_t want = (uint64_t)(META_USED | META_DIRTY | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
           for (;;) {
             const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[hh]), 0ull, (unsigned long long)want);
             if (prev == 0) { won = true; break; }
@@ -1227,7 +1265,7 @@ __device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* ta
         const SubCtr* sc = row_subs(arena, k.new_base, lg);
         for (uint32_t i = 0; i < SUBS; i++) count += sc[i].cnt;
       }
-      d.meta = META_USED | (lg << META_LG_SHIFT);
+      d.meta = META_USED | META_DIRTY | (lg << META_LG_SHIFT);
       d.base = k.new_base;
       d.used = count;
       if (lg >= BIG_LG) {
@@ -1550,6 +1588,67 @@ __global__ __launch_bounds__(256) void k_cf_neighbors(DirSlot* dir, uint32_t dma
       if (written > cap) written = cap;
     }
     if (lane == 0) counts[r] = written;
+  }
+}
+
+// ---- persistence: dirty rows (src/smatrix.c:418-425 rmap_sync_defer, :929-960 the IO thread's queue) --------
+// k_dirty_collect: every directory slot marked META_DIRTY is copied to `out` and unmarked (one list reservation per
+// workgroup).  With all != 0 every row is taken (first write of a file, compaction).
+__global__ __launch_bounds__(256) void k_dirty_collect(DirSlot* dir, uint32_t dir_size, uint32_t all, DirSlot* out,
+                                                       uint32_t cap, uint32_t* count) {
+  __shared__ uint32_t l_n, l_base;
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < dir_size; i0 += gridDim.x * blockDim.x) {     // block-uniform
+    if (threadIdx.x == 0) l_n = 0;
+    __syncthreads();
+    const uint32_t i = i0 + threadIdx.x;
+    DirSlot d = {0, 0, 0, 0};
+    bool take = false;
+    if (i < dir_size) {
+      d = dir[i];
+      take = (d.meta & META_USED) && d.base != 0 && (all || (d.meta & META_DIRTY));
+    }
+    uint32_t rank = 0;
+    if (take) rank = atomicAdd(&l_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && l_n) l_base = atomicAdd(count, l_n);
+    __syncthreads();
+    if (take) {
+      if (d.meta & META_DIRTY) dir[i].meta = d.meta & ~META_DIRTY;
+      const uint32_t at = l_base + rank;
+      if (at < cap) { d.meta &= ~META_DIRTY; out[at] = d; }
+    }
+    __syncthreads();
+  }
+}
+
+// k_pack_rows: row tables -> a staging buffer laid out like the FILE (RMAP block = 8 x 0x23, u64 n_slots, the
+// raw cells: src/smatrix.c:57-70), so that a window of it goes out with one pwrite.  One wave per row, 16-byte
+// moves; big rows add their sub-counter sums nowhere (the file holds cells only).
+struct PackRow {
+  uint32_t base;       // arena unit of the row's cells
+  uint32_t lg;         // log2(cells)
+  uint64_t out;        // byte offset in the staging buffer of the block's first byte (header if with_head)
+  uint32_t with_head;  // 1: header + cells (a new block), 0: cells only (rewrite in place)
+  uint32_t pad;
+};
+__global__ __launch_bounds__(256) void k_pack_rows(uint32_t n, const PackRow* rows, const uint8_t* arena, uint8_t* stage) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    const PackRow w = rows[r];
+    const uint4* src = reinterpret_cast<const uint4*>(arena + (uint64_t)w.base * UNIT_BYTES);
+    uint8_t* dst = stage + w.out;
+    if (w.with_head) {
+      if (lane == 0) {
+        uint64_t* h = reinterpret_cast<uint64_t*>(dst);
+        h[0] = 0x2323232323232323ull;
+        h[1] = 1ull << w.lg;
+      }
+      dst += 16;
+    }
+    uint4* d4 = reinterpret_cast<uint4*>(dst);                     // 16-byte aligned: offsets are multiples of 8 + 16
+    const uint32_t n16 = (8u << w.lg) / 16u;
+    for (uint32_t i = lane; i < n16; i += 64) d4[i] = src[i];
   }
 }
 

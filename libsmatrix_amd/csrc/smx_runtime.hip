@@ -346,6 +346,10 @@ struct Matrix {
   CellCache cache;                      // scalar ABI: mirrored cells (see CellCache)
   DevBuf<uint64_t> row_ret;             // scalar getrow: pooled device buffer for rows that outgrow the pinned one
   uint32_t* h_row = nullptr;            // pinned: {count, spare, big[2], offsets[2] (u64)} + pairs written by the kernel itself
+  void* file_index = nullptr;           // FileIndex (smx_file.inc): where every row lives in the backing file
+  bool file_fsync = false;              // SMATRIX_FSYNC=1: fsync between the row blocks and the CMAP entries, and after
+  uint64_t flush_every = 0;             // SMATRIX_FLUSH_EVERY=N: checkpoint the file after every N write batches
+  uint64_t dbg_after = 0;               // SMATRIX_DBG_AFTER: batch number from which a measurement build's debug mode applies
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
 };
 
@@ -538,6 +542,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   m->defer[1].need(n);
   if (op == OP_SET) m->cellp.need(n);
   m->st.batches++;
+  if (m->dbg_after && m->st.batches == m->dbg_after) {     // measurement builds (SMX_AGG_DBG): switch the kernel's debug mode on
+    const uint32_t one = 1;
+    HIP_OK(hipMemcpyAsync(&m->d_ctl->pad1, &one, 4, hipMemcpyHostToDevice, s));
+  }
 
   uint32_t cur_n = n;
   const uint32_t* idx = nullptr;
@@ -631,6 +639,8 @@ void refresh_public(smatrix_t* self) {
   self->mem = (uint64_t)m->dir_size * sizeof(DirSlot) + live_units * UNIT_BYTES;
 }
 
+void file_flush(smatrix_t* self, Matrix* m, bool all);
+
 void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, const uint32_t* y,
                       const uint32_t* v, uint32_t* out, hipStream_t s) {
   Matrix* m = M(self);
@@ -638,6 +648,12 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
   if (op == OP_GET) run_get(m, (uint32_t)n, x, y, out, s);
   else run_write(m, op, (uint32_t)n, x, y, v, out, s);
   refresh_public(self);
+  // SMATRIX_FLUSH_EVERY=N: the backing file is brought up to date after every N-th write batch (the reference's IO
+  // thread writes dirty rows behind the caller's back all the time, src/smatrix.c:929-960; here it is a checkpoint)
+  if (op != OP_GET && m->flush_every && self->fd && m->st.batches % m->flush_every == 0) {
+    HIP_OK(hipStreamSynchronize(s));
+    file_flush(self, m, false);
+  }
 }
 
 // Writes the scalar ABI's mirrored values back (one batched set of cells that all exist: no structure change) before
@@ -671,6 +687,17 @@ void cache_sync(Matrix* m, bool drop) {
 
 // ---- C ABI -----------------------------------------------------------------------
 extern "C" {
+
+// include/smatrix_batch.h: everything written so far reaches the backing file now (no-op in memory mode)
+int smatrix_flush(smatrix_t* self) {
+  Matrix* m = M(self);
+  if (m->fname.empty() || !self->fd) return 0;
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
+  if (m->dirty) file_flush(self, m, false);
+  return 0;
+}
 
 int smatrix_device_available(void) {
   int n = 0;
@@ -717,6 +744,9 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
   m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* a = getenv("SMATRIX_DBG_AFTER")) m->dbg_after = strtoull(a, nullptr, 10);
+  if (const char* a = getenv("SMATRIX_FSYNC")) m->file_fsync = *a == '1';
+  if (const char* a = getenv("SMATRIX_FLUSH_EVERY")) m->flush_every = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
@@ -744,10 +774,7 @@ void smatrix_close(smatrix_t* self) {
     {
       std::lock_guard<std::mutex> g(m->mu);
       cache_sync(m, true);
-      if (!m->fname.empty() && self->fd && m->dirty) {     // a matrix that was only read has nothing to persist
-        if (m->io_threads > 1) file_store(self, m);
-        else file_store_serial(self, m);
-      }
+      if (!m->fname.empty() && self->fd && m->dirty) file_flush(self, m);   // a matrix that was only read has nothing to persist
       (void)hipStreamSynchronize(m->stream);
       PhaseClock clk(m->trace_rounds, "close");
       m->arena.destroy();
@@ -774,6 +801,7 @@ void smatrix_close(smatrix_t* self) {
       close(self->fd);
       clk.lap("close(fd)");
     }
+    file_index_free(m);
     delete m;
   }
   free(self);
@@ -1347,3 +1375,6 @@ void smx_stream_release_device(smx_stream_t* st) {
 }
 
 }  // extern "C"
+
+// ---- the multi-GPU router (include/smatrix_shard.h) ---------------------------------------------------
+#include "smx_shard.inc"

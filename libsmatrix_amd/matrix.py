@@ -165,6 +165,10 @@ class SparseMatrix:
             out["kernel_ops_" + op] = st.kernel_ops[i]
         return out
 
+    def flush(self):
+        """file mode: dirty rows reach the backing file now (include/smatrix_batch.h smatrix_flush)"""
+        self._lib.smatrix_flush(self._h)
+
     def profile(self, on=True):
         self._lib.smatrix_profile(self._h, int(on))
 

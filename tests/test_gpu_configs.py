@@ -215,6 +215,73 @@ def test_scalar_abi_mirror_with_threads(G):
     m.close()
 
 
+def test_incremental_flush_writes_dirty_rows_only(G, oracle_mod, tmp_path):
+    """Persistence the reference's way (src/smatrix.c:418-496, :744-788): smatrix_flush writes the rows that changed
+    since the last flush -- in place when the table kept its size, as a fresh block with a re-pointed CMAP entry when
+    it grew, as a new CMAP entry when the row is new -- and nothing else; a process that dies without smatrix_close
+    leaves the state of the last flush (copy of the file taken while the matrix is still open); every stage is read
+    back by the oracle (and by the compiled reference where present) and by this library's own loader."""
+    import shutil
+    rng = np.random.default_rng(17)
+    path = str(tmp_path / "inc.smx")
+    g, o = G(path), oracle_mod.Oracle()
+    readers = [oracle_mod.Oracle] + ([oracle_mod.Reference] if oracle_mod.have_reference() else [])
+
+    def check(tag, qx, qy):
+        snap = str(tmp_path / ("snap_%s.smx" % tag))
+        shutil.copy(path, snap)                              # what a crash right now would leave behind
+        want = o.apply(0, qx, qy)
+        rows = np.unique(qx)
+        for R in readers:
+            r = R(snap)
+            assert (r.apply(0, qx, qy) == want).all(), (tag, R.__name__)
+            assert [r.rowlen(int(a)) for a in rows[:300]] == [o.rowlen(int(a)) for a in rows[:300]], (tag, R.__name__)
+            r.close()
+        return os.path.getsize(snap)
+
+    x = rng.integers(0, 5000, 300000, dtype=np.uint32); y = rng.integers(1, 1 << 20, 300000, dtype=np.uint32)
+    v = rng.integers(1, 9, x.size, dtype=np.uint32)
+    g.apply(2, x, y, v); o.apply(2, x, y, v)
+    g.m.flush()
+    st = g.stats()
+    assert st["file_flushes"] == 1 and st["file_rows_written"] == 5000
+    size1 = check("first", x, y)
+    g.m.flush()                                              # nothing changed: nothing written
+    assert g.stats()["file_rows_written"] == 5000
+    # values only, in 40 rows: rewritten in place, the file keeps its length
+    hot = np.nonzero(x < 40)[0]
+    g.apply(2, x[hot], y[hot], v[hot]); o.apply(2, x[hot], y[hot], v[hot])
+    g.m.flush()
+    assert g.stats()["file_rows_written"] == 5000 + 40
+    assert check("inplace", x, y) == size1
+    # new keys: rows 100..199 grow (fresh blocks, entries re-pointed), rows 9000..9049 are new (new CMAP entries);
+    # a scalar call on a mirrored cell rides along (the flush writes the mirror back first)
+    x2 = np.concatenate([rng.integers(100, 200, 40000, dtype=np.uint32), rng.integers(9000, 9050, 5000, dtype=np.uint32)])
+    y2 = rng.integers(1, 1 << 20, x2.size, dtype=np.uint32)
+    g.apply(2, x2, y2, np.ones_like(x2)); o.apply(2, x2, y2, np.ones_like(x2))
+    assert g.incr(7, 123456789, 5) == o.incr(7, 123456789, 5) and g.incr(7, 123456789, 2) == o.incr(7, 123456789, 2)
+    g.m.flush()
+    written = g.stats()["file_rows_written"] - 5040
+    assert 150 <= written <= 151 + 0, written               # 100 grown + 50 new + row 7
+    qx, qy = np.concatenate([x, x2, [7]]).astype(np.uint32), np.concatenate([y, y2, [123456789]]).astype(np.uint32)
+    size3 = check("grown", qx, qy)
+    assert size3 > size1
+    # unflushed work is lost by a crash, but the file stays the last checkpoint
+    g.apply(2, x[:1000], y[:1000], v[:1000])
+    snap = str(tmp_path / "crash.smx"); shutil.copy(path, snap)
+    r = oracle_mod.Oracle(snap); assert (r.apply(0, qx, qy) == o.apply(0, qx, qy)).all(); r.close()
+    o.apply(2, x[:1000], y[:1000], v[:1000])
+    g.close()                                                # the last flush
+    # our own loader takes the file (leaked blocks, re-pointed entries and all), writes on, flushes incrementally again
+    g = G(path)
+    assert (g.apply(0, qx, qy) == o.apply(0, qx, qy)).all()
+    g.apply(2, x2[:3000], y2[:3000] + 7, np.ones(3000, np.uint32)); o.apply(2, x2[:3000], y2[:3000] + 7, np.ones(3000, np.uint32))
+    g.m.flush()
+    assert 0 < g.stats()["file_rows_written"] <= 150
+    check("reloaded", np.concatenate([qx, x2[:3000]]), np.concatenate([qy, y2[:3000] + 7]))
+    g.close(); o.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 def test_reference_benchmark_binary_through_the_shim(oracle_mod, tmp_path):
     """The reference's UNCHANGED src/smatrix_benchmark.c, compiled on the build box against include/smatrix.h and
