@@ -461,6 +461,9 @@ def main():
                     help="test rig: every rank uses cuda:0 and the exchange is staged through the host (gloo)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="route through ShardedMatrix even with one rank (exercises the exchange path)")
+    ap.add_argument("--c-router", action="store_true",
+                    help="sharded path through the C library's own router (smatrix_shard_apply_then_get_dev: RCCL send/recv "
+                         "issued by the library, one partition + one record exchange per incr+get step)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
                     help="2 (default): the metric's workload; 3: getrow scan of the 13M-row CF matrix; 5: file round trip of it (one GPU)")
     ap.add_argument("--rows", type=int, default=None, help="--config 3/5: rows of the CF matrix (default 13M)")
@@ -468,6 +471,11 @@ def main():
                     help="config 2 only: skip the legs that are not `value` (reference-checksum replay, sustained run, dense ids, configs 3/5)")
     ap.add_argument("--sustain-s", type=float, default=1.5, help="seconds of the sustained (continuing-stream) leg")
     args = ap.parse_args()
+
+    # ONE JSON line on stdout: everything else that libraries print there (RCCL's version banner at communicator
+    # creation, for one) is sent to stderr for the whole run
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -492,7 +500,7 @@ def main():
         line.update({"n_gpus": 1, "steps": 1, "warmup": 0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                      "dtype": "u32", "data": "synthetic", "config": {"workload": r["workload"]},
                      "roofline": r.get("roofline") or r["getrow_after_reopen"]["roofline"], "detail": r})
-        print(json.dumps(line))
+        print(json.dumps(line), file=json_out, flush=True)
         return
     sharded = world > 1 or args.force_sharded
     if sharded:
@@ -530,7 +538,10 @@ def main():
         gen.fill_device(s * B, B, xs[s].data_ptr(), ys[s].data_ptr(), stream)
     torch.cuda.synchronize()
 
-    if sharded:
+    if sharded and args.c_router:
+        from libsmatrix_amd.sharded import NativeShardedMatrix
+        m = NativeShardedMatrix()
+    elif sharded:
         from libsmatrix_amd.sharded import ShardedMatrix
         m = ShardedMatrix()
     else:
@@ -543,7 +554,7 @@ def main():
     # the host before a collective can be issued) run under the host-driven rounds of the op kernels instead of
     # in front of them.  The library calls release the GIL; the op kernels stay on the main thread.
     comm = None
-    if sharded and not args.no_overlap and not args.no_comm_thread:
+    if sharded and not args.no_overlap and not args.no_comm_thread and not args.c_router:
         from concurrent.futures import ThreadPoolExecutor
         comm = ThreadPoolExecutor(max_workers=1, initializer=lambda: torch.cuda.set_device(local))
 
@@ -569,6 +580,8 @@ def main():
         lagging[:] = [h_i, h_g]
 
     def step(s):
+        if args.c_router and sharded:
+            return m.apply_then_get_dev(OP_INCR, xs[s], ys[s], ones, out_i, out_g, stream)
         if comm is not None:
             return step_threaded(s)
         if sharded and not args.no_overlap:
@@ -619,7 +632,7 @@ def main():
         loads = [None] * world
         dist.all_gather_object(loads, int(m.exchanged_ops))
         mean = max(sum(loads) / world, 1)
-        shard_info = {"rows_placed_by_load": len(m.placement.place),
+        shard_info = {"router": "C library (RCCL send/recv groups)", "ops_applied_over_mean": [round(v / mean, 3) for v in loads]} if args.c_router else {"rows_placed_by_load": len(m.placement.place),
                       "hash_range_widths": ([round((b - a) / 2.0 ** 32, 4) for a, b in
                                              zip([0] + m.placement.cuts, m.placement.cuts + [1 << 32])]
                                             if m.placement.cuts is not None else "equal"),
@@ -722,7 +735,7 @@ def main():
             res["random_access"] = ra
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(1 << args.cpu_sample_lg, torch, dev)
-        print(json.dumps(res))
+        print(json.dumps(res), file=json_out, flush=True)
     if comm is not None:
         comm.shutdown()
     m.close()

@@ -550,3 +550,81 @@ class _null_ctx:
 
     def __exit__(self, *a):
         return False
+
+
+class NativeShardedMatrix:
+    """The router that lives in the C library (include/smatrix_shard.h, csrc/smx_shard.inc): the library partitions,
+    exchanges counts / records / results with grouped ncclSend/ncclRecv over RCCL and applies -- Python only hands
+    the 128-byte RCCL id from rank 0 to the other ranks (here through torch.distributed when it is initialised;
+    any launcher can do that) and passes device pointers.  Every call is collective."""
+
+    def __init__(self, filename=None, rank=None, world=None, unique_id=None):
+        self._lib = _lib.load()
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world = rank, world
+        if world > 1 and unique_id is None:
+            box = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                if self._lib.smatrix_shard_unique_id(buf):
+                    raise RuntimeError("RCCL is not available (smatrix_shard_unique_id)")
+                box[0] = bytes(buf.raw)
+            dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id else None
+        self._h = self._lib.smatrix_shard_open(filename.encode() if filename else None, rank, world, idbuf)
+        if not self._h:
+            raise ValueError("smatrix_shard_open() failed")
+        self.local = _BorrowedMatrix(self._lib, self._lib.smatrix_shard_local(self._h))
+
+    def apply_dev(self, op, x, y, v, out, stream=None):
+        n = x.numel()
+        self._lib.smatrix_shard_apply_dev(self._h, op, n, x.data_ptr(), y.data_ptr(),
+                                          v.data_ptr() if v is not None else None, out.data_ptr(), stream)
+
+    def apply_then_get_dev(self, op, x, y, v, out, out_get, stream=None):
+        self._lib.smatrix_shard_apply_then_get_dev(self._h, op, x.numel(), x.data_ptr(), y.data_ptr(), v.data_ptr(),
+                                                   out.data_ptr(), out_get.data_ptr(), stream)
+
+    def set_placement(self, placement):
+        """a Placement (plan_placement) -> the library's device tables; identical on every rank"""
+        import numpy as np
+        cuts = np.array(placement.cuts, dtype=np.uint32) if placement.cuts is not None else None
+        slots, table = 0, None
+        if placement.place:
+            slots = 16
+            while slots < 2 * len(placement.place):
+                slots *= 2
+            table = np.zeros((slots, 2), dtype=np.uint32)
+            for x, owner in sorted(placement.place.items()):
+                i = self._lib.smatrix_place_slot(x, slots)
+                while table[i, 1]:
+                    i = (i + 1) % slots
+                table[i] = (x, owner + 1)
+        rc = self._lib.smatrix_shard_set_placement(
+            self._h, cuts.ctypes.data_as(C.c_void_p) if cuts is not None else None,
+            table.ctypes.data_as(C.c_void_p) if table is not None else None, slots)
+        if rc:
+            raise ValueError("smatrix_shard_set_placement failed")
+
+    @property
+    def exchanged_ops(self):
+        return int(self._lib.smatrix_shard_ops_applied(self._h))
+
+    def close(self):
+        if self._h:
+            self.local._h = None
+            self._lib.smatrix_shard_close(self._h)
+            self._h = None
+
+
+class _BorrowedMatrix(SparseMatrix):
+    """the local shard of a NativeShardedMatrix as a SparseMatrix (owned and closed by the shard handle)"""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h, self.filename = lib, handle, None
+
+    def close(self):
+        self._h = None

@@ -215,6 +215,49 @@ def test_scalar_abi_mirror_with_threads(G):
     m.close()
 
 
+def test_native_router_one_rank(G, oracle_mod, tmp_path):
+    """include/smatrix_shard.h router section, the C library's own multi-GPU path, with all a 1-GPU box allows: one
+    rank.  The batch still goes through the partition kernels, the (self-)exchange, the packed in-place apply and the
+    result gather; answers and tables must be the oracle's, apply_then_get must equal apply + get, a planned placement
+    must not change anything, and the shard's file must be readable by the oracle."""
+    import torch
+    from libsmatrix_amd.sharded import NativeShardedMatrix, Placement
+    rng = np.random.default_rng(23)
+    dev = torch.device("cuda", 0)
+    path = str(tmp_path / "shard0.smx")
+    sh, o = NativeShardedMatrix(path, rank=0, world=1), oracle_mod.Oracle()
+    sh.set_placement(Placement(1, None, {5: 0, 77: 0, 123456: 0}))
+    t = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    for rnd, (op, n) in enumerate(((2, 300000), (2, 100000), (1, 50000), (2, 1 << 21))):      # (no decr: a value-0 cell is dropped
+        # by the reference's load rule, quirk Q4, and WHICH chains that cuts depends on the batch layout)
+        x = rng.integers(0, 20000, n, dtype=np.uint32); y = rng.integers(1, 5000, n, dtype=np.uint32)
+        v = ((x + y) % 4 + 1).astype(np.uint32)                     # one value per key: order-free returns
+        dx, dy, dv = t(x), t(y), t(v)
+        out = torch.empty(n, dtype=torch.int32, device=dev); outg = torch.empty_like(out)
+        if rnd % 2 == 0:
+            sh.apply_then_get_dev(op, dx, dy, dv, out, outg)
+        else:
+            sh.apply_dev(op, dx, dy, dv, out)
+            sh.apply_dev(0, dx, dy, None, outg)
+        torch.cuda.synchronize()
+        want = o.apply(op, x, y, v)
+        got = out.cpu().numpy().view(np.uint32)
+        if op == 1:
+            assert (got == v).all()
+        else:
+            ka = np.lexsort((got, x.astype(np.uint64) << 32 | y)); kb = np.lexsort((want, x.astype(np.uint64) << 32 | y))
+            assert (got[ka] == want[kb]).all(), rnd
+        assert (outg.cpu().numpy().view(np.uint32) == o.apply(0, x, y)).all(), rnd
+    assert sh.exchanged_ops > 0
+    rows = o.list_rows()
+    assert (sh.local.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], np.uint32)).all()
+    assert int(sh.local.stats()["rows"]) == rows.size
+    sh.close()
+    back = oracle_mod.Oracle(path)
+    assert [back.rowlen(int(r)) for r in rows[:500]] == [o.rowlen(int(r)) for r in rows[:500]]
+    back.close(); o.close()
+
+
 def test_incremental_flush_writes_dirty_rows_only(G, oracle_mod, tmp_path):
     """Persistence the reference's way (src/smatrix.c:418-496, :744-788): smatrix_flush writes the rows that changed
     since the last flush -- in place when the table kept its size, as a fresh block with a re-pointed CMAP entry when
