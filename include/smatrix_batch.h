@@ -22,6 +22,10 @@
  * Results are complete in stream order: writers return after their last round has
  * finished on that stream, get/rowlen/getrow may return as soon as they are enqueued;
  * with hip_stream == NULL every call synchronises before returning).
+ * ORDERING: the library's lock serialises host code only.  All calls on one handle must reach the GPU in one order:
+ * use ONE stream per handle, or order the streams yourself (events) -- a get/rowlen/getrow enqueued on stream A
+ * and a later write on stream B would otherwise race on the tables (a write may grow rows, recycle their old
+ * blocks and replace the directory).  hip_stream == NULL and the host-pointer calls always synchronise.
  * Return value: 0 on success; failures abort like the scalar API.
  * n must be < 2^32.
  */

@@ -911,7 +911,9 @@ void launch_getrow(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* x, cons
   uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
   hipLaunchKernelGGL(k_getrow, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x,
                      off, ret, counts, m->big.p);
-  hipLaunchKernelGGL(k_getrow_big, dim3(512), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
+  // rows of more than 8192 cells were only noted down: a workgroup per row, at most the rows asked for (with none
+  // noted the launch is a few idle workgroups)
+  hipLaunchKernelGGL(k_getrow_big, dim3(std::min<uint32_t>(n, 512)), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
                      x, off, ret, counts, m->big.p);
   HIP_OK(hipGetLastError());
 }

@@ -1,8 +1,18 @@
 #!/usr/bin/env python3
 """Turns the raw outputs of tools/refresh_profiles.sh (gpurun_out/prof_*) into the files committed under profiles/:
-r01_bench.json, r01_rocprof_kernel_stats.txt, r01_pmc_summary.txt, r01_pmc.json."""
-import json, os, re, shutil, sys
+r02_bench.json, r02_rocprof_kernel_stats.txt, r02_pmc_summary.txt, pmc.json (keyed to the kernel source hash), r02_getrow_config3.txt."""
+import hashlib, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = "r02"
+
+
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for f in ("smx_kernels.hpp", "smx_runtime.hip"):
+        h.update(open(os.path.join(ROOT, "libsmatrix_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 raw = open(os.path.join(G, "prof_pmc_raw.txt")).read()
 AGG, GET = "smx::k_apply_agg<2, 1u>", "smx::k_apply<0>"
@@ -25,8 +35,8 @@ bytes_agg = (agg["fetch"] + agg["write"]) * 1024; bytes_get = (get["fetch"] + ge
 rd_agg = agg["miss"] - agg["atom"]
 t_agg = rd_agg / (R * 1e9) + agg["atom"] / (A * 1e9); t_get = get["miss"] / (R * 1e9)
 ki, kg = b["roofline"]["avg_launch_ms"], b["roofline_get"]["avg_launch_ms"]
-hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --no-cpu   (three separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; tools/refresh_profiles.sh + tools/build_profiles.py)
-# MI355X, round 1 (final code of the round), config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
+hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --no-cpu --no-extras   (three separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; tools/refresh_profiles.sh + tools/build_profiles.py)
+# MI355X, round 2, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
 # Calibration in our own access pattern, same runs: k_probe_random<0> = 2^27 random 8-byte loads over 4 GiB -> %.0f KiB = %.1f B per touch
 #   (a 64 B line per touch; no 1/2 correction for this shape); k_probe_random<1>/<2> = 2^27 scattered 32-bit atomics -> WRITE_SIZE 32 B and TCC_EA0_ATOMIC 1.0 per atomic.
 #   (the guide's gfx950 correction -- FETCH_SIZE tallies a 128-B coalesced streaming request at 64 B -- applies only to the streamed op arrays,
@@ -40,7 +50,8 @@ hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- pytho
 # so the read misses of the incr kernel are TCC_MISS - TCC_EA0_ATOMIC; they include the streamed op arrays (12 B/op in = 3.1 M lines).
 #   k_apply_agg<INCR>: %.1f M read misses / %.1f G/s + %.1f M atomics / %.1f G/s = %.3f ms;  measured %.3f ms per launch (HIP events, growing table;
 #                      1.30 ms when every key is a hit) -> %.0f %% of that bound.  The atomics are 80 %% of it: one returning atomic per distinct key of a
-#                      2048-op tile (+ a ticket and a claim per new cell) -- the LDS fold removes the duplicates inside a tile, not across tiles.
+#                      2048-op tile (+ a ticket and a claim per new cell) -- the LDS fold removes the duplicates inside a tile, not across tiles
+#                      (how the kernel's time splits over these classes: profiles/r02_agg_kernel_phase_shares.txt).
 #   k_apply<GET>     : %.1f M misses / %.1f G/s = %.3f ms;  measured %.3f ms -> %.0f %%
 #   i.e. the kernels run within 15-30 %% of the chip's random-transaction rates for what they touch; the rest of the gap to the byte roofline is the COUNT
 #   (two lines per op, 64 B moved per 8-16 B used).
@@ -48,22 +59,52 @@ hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- pytho
        100 * agg["hit"] / (agg["hit"] + agg["miss"]), get["fetch"], get["write"], bytes_get, bytes_get / N,
        100 * get["hit"] / (get["hit"] + get["miss"]), R, A, rd_agg / 1e6, R, agg["atom"] / 1e6, A, t_agg * 1e3, ki,
        100 * t_agg * 1e3 / ki, get["miss"] / 1e6, R, t_get * 1e3, kg, 100 * t_get * 1e3 / kg)
-open(os.path.join(P, "r01_pmc_summary.txt"), "w").write(hdr + raw)
-json.dump({"source": "profiles/r01_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py --no-cpu`, calibrated on k_probe_random in the same runs: 64 B per random 8-byte load, 32 B per atomic)",
+open(os.path.join(P, RND + "_pmc_summary.txt"), "w").write(hdr + raw)
+json.dump({"summary": "profiles/%s_pmc_summary.txt" % RND, "kernel_source_sha16": kernel_source_sha16(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_* in separate passes of `python3 bench.py --no-cpu --no-extras`",
            "k_apply_agg_incr": {"fetch_kib": agg["fetch"], "write_kib": agg["write"], "bytes_per_launch": int(bytes_agg), "ops_per_launch": N,
                                 "l2_misses": agg["miss"], "memory_side_atomics": agg["atom"]},
            "k_apply_get": {"fetch_kib": get["fetch"], "write_kib": get["write"], "bytes_per_launch": int(bytes_get), "ops_per_launch": N,
-                           "l2_misses": get["miss"]}}, open(os.path.join(P, "r01_pmc.json"), "w"), indent=1)
+                           "l2_misses": get["miss"]}}, open(os.path.join(P, "pmc.json"), "w"), indent=1)
 ur = json.load(open(os.path.join(G, "prof_bench_under_rocprof.json")))
-open(os.path.join(P, "r01_rocprof_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu   (MI355X, round 1 final, tools/refresh_profiles.sh; bench line of this "
+open(os.path.join(P, RND + "_rocprof_kernel_stats.txt"), "w").write(
+    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 2, tools/refresh_profiles.sh; bench line of this "
     "same profiled run: %.0f Mops/s, k_apply_agg<INCR> round-0 avg %.3f ms and k_apply<GET> %.3f ms by HIP events; the full-batch grids below include the 4 all-hit "
     "replays of the steady-state extra and the first batches of the empty table)\n" % (ur["value"], ur["roofline"]["avg_launch_ms"], ur["roofline_get"]["avg_launch_ms"])
     + open(os.path.join(G, "prof_kernel_stats.txt")).read()
     + "\n# per-step spans of the same trace (tools/step_spans.py): span, busy, idle, kernels, prep rounds | top kernels (us)\n"
     + open(os.path.join(G, "prof_step_spans.txt")).read() + "\n# kernel timeline of step 23 (tools/timeline.py)\n"
     + open(os.path.join(G, "prof_timeline_step23.txt")).read())
-# the bench line must carry the traffic of THIS refresh: bench.py reads profiles/r01_pmc.json, which was just rewritten
+# the bench line must carry the traffic of THIS refresh: bench.py reads profiles/pmc.json, which was just rewritten
 b["roofline"]["traffic"] = int(bytes_agg); b["roofline_get"]["traffic"] = int(bytes_get)
-json.dump(b, open(os.path.join(P, "r01_bench.json"), "w"))
+b["roofline"]["memory_side_atomics"] = agg["atom"]
+json.dump(b, open(os.path.join(P, RND + "_bench.json"), "w"))
 print(hdr)
+# config 3: the getrow scan
+raw3 = open(os.path.join(G, "prof_pmc_raw_config3.txt")).read()
+ks3 = open(os.path.join(G, "prof_kernel_stats_config3.txt")).read()
+c3 = json.load(open(os.path.join(G, "prof_bench_config3_under_rocprof.json")))
+
+
+def val3(kern, ctr):
+    m = re.search(r"%s\s+grid=\d+\s+%s\s+dispatches=\s*(\d+) mean=\s*([\d.]+)" % (re.escape(kern), ctr), raw3)
+    return float(m.group(2)) if m else None
+
+
+f3, w3 = val3("smx::k_getrow", "FETCH_SIZE"), val3("smx::k_getrow", "WRITE_SIZE")
+d3 = c3["detail"]
+lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 2" % (d3["rows"], d3["nnz"]),
+         "# bench line of the profiled run: getrow %.3f ms = %.1f G nnz/s; algorithmic %.0f GB/s = %.3f of the 8 TB/s peak; build %.2f s (%.2f G ops/s)"
+         % (d3["getrow_ms"], d3["Gnnz_per_s"], d3["roofline"]["achieved"], d3["roofline"]["frac"], d3["build_s"], d3["build_Gops_per_s"])]
+if f3 and w3:
+    # k_getrow streams the row tables with 16-byte loads: the guide's gfx950 correction applies (FETCH_SIZE tallies 128-B requests at 64 B)
+    moved = f3 * 1024 * 2 + w3 * 1024
+    lines.append("# PMC (separate passes): FETCH_SIZE %.0f KiB (x2 by the gfx950 streaming correction) + WRITE_SIZE %.0f KiB = %.3e B per launch"
+                 " = %.2f TB/s over %.3f ms; model: %d B" % (f3, w3, moved, moved / (d3["getrow_ms"] * 1e-3) / 1e12, d3["getrow_ms"], d3["roofline"]["bytes_moved_model"]))
+if f3 and w3:
+    pj = json.load(open(os.path.join(P, "pmc.json")))
+    pj["k_getrow"] = {"fetch_kib": f3, "write_kib": w3, "bytes_per_launch": int(moved), "rows": d3["rows"], "nnz": d3["nnz"],
+                      "note": "FETCH_SIZE doubled (gfx950: 128-B streaming requests are tallied at 64 B)"}
+    json.dump(pj, open(os.path.join(P, "pmc.json"), "w"), indent=1)
+open(os.path.join(P, RND + "_getrow_config3.txt"), "w").write("\n".join(lines) + "\n" + ks3 + "\n" + raw3)
+json.dump(c3, open(os.path.join(P, RND + "_bench_config3.json"), "w"))
