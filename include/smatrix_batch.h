@@ -100,6 +100,8 @@ typedef struct {
   uint64_t scalar_cache_hits;    /* scalar-ABI calls answered from the host-side cell mirror (no device round trip) */
   uint64_t scalar_cache_flushes; /* write-backs of mirrored values (one batched set each) */
   uint64_t scalar_cache_flushed_cells;
+  uint64_t bulk_rounds;          /* write batches whose deferred ops were grouped by row (the bulk path, k_fix_*) */
+  uint64_t bulk_ops;             /* ops finished on that path */
   uint64_t file_flushes;         /* file mode: write-outs of dirty rows (smatrix_flush, SMATRIX_FLUSH_EVERY, close) */
   uint64_t file_rows_written;    /* rows those write-outs wrote (a clean row is never rewritten) */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,

@@ -16,7 +16,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rows", "dir_slots", "arena_units", "arena_mapped", "arena_free_units", "batches", "rounds",
         "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced", "long_probe_rounds", "scalar_cache_hits", "scalar_cache_flushes",
-        "scalar_cache_flushed_cells", "file_flushes", "file_rows_written")] + [
+        "scalar_cache_flushed_cells", "bulk_rounds", "bulk_ops", "file_flushes", "file_rows_written")] + [
         ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
 
 

@@ -699,7 +699,8 @@ __device__ __forceinline__ void prep_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl, uint32_t st) {
+    FreeLists fl, uint32_t st, uint32_t create_only) {
+  // create_only: rows are created, nothing is flagged for growth (the bulk path decides growth itself, k_fix_rows)
   // block-scope scratch of the row-creation step
   __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
   __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
@@ -831,6 +832,7 @@ __device__ __forceinline__ void prep_body(
     bool absent = false;
     uint32_t base = 0, lg = 0;
     LongProbe lp{false, nullptr, 0, 0};
+    if (create_only) continue;                      // (block-uniform)
     if (live && !missing && Y != 0) {
       base = dir[h].base;          // plain: 0 only for a row created in this very launch
       if (base != 0) {
@@ -927,8 +929,520 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl, uint32_t st) {
-  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st);
+    FreeLists fl, uint32_t st, uint32_t create_only) {
+  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st, create_only);
+}
+
+// ---- the bulk path: many deferred ops (bulk loads, the first batches of a matrix) ---------------------------
+// A batch that CREATES its rows defers every op in round 0, and a new 115-key row then needs one round per doubling
+// (create, 16 -> 32 -> ... -> 256: six rounds, each re-running the op kernel over everything still pending -- the
+// config-3 build ran at 1 G ops/s against 12 G in steady state).  Here the deferred ops are grouped by row instead
+// (count per directory slot, exclusive scan, scatter) and ONE WAVE per row then does what the reference does for that
+// row's ops in list order -- smatrix_rmap_insert with its `used > size/2` test, smatrix_rmap_resize re-inserting in
+// old slot order (src/smatrix.c:343-416) -- on a table held in LDS, start to finish, and writes the final table out
+// once.  The sequential core is the reference's algorithm itself (one lane; the row's ops are staged and its results
+// written back by all 64), so sizes, `used` and the layout are those of a legal serialisation by construction.
+// Rows that would outgrow FIX_MAX_LG cells, big rows, rows that are missing and ops with y == 0 are handed back to the
+// round loop through a new deferred list.
+#ifndef SMX_FIX_MAX_LG
+#define SMX_FIX_MAX_LG 9
+#endif
+constexpr uint32_t FIX_MAX_LG = SMX_FIX_MAX_LG;          // final table <= 512 cells: 2 x 4 KB + 2 KB of LDS per wave
+constexpr uint32_t FIX_WAVES = 4;                        // waves (rows in flight) per workgroup
+constexpr uint32_t FIX_NONE = 0xFFFFFFFFu;
+
+// smallest lg with n <= 2^lg / 2 + 1 keys (src/smatrix.c:346 read backwards), at least `lg0`
+__host__ __device__ inline uint32_t fix_lg_for(uint32_t n, uint32_t lg0) {
+  uint32_t lg = lg0 < ROW_FIRST_LG ? ROW_FIRST_LG : lg0;
+  while (lg < 31 && n > (1u << lg) / 2u + 1u) lg++;
+  return lg;
+}
+
+// the largest table a row with `used` keys can end at when c ops are applied to it: every op a new key, plus one for the
+// (0,v) cell of quirk Q1, which `used` leaves out until the next resize counts it (src/smatrix.c:353-354 vs :299)
+__host__ __device__ inline uint32_t fix_bound_lg(uint32_t used, uint32_t c, uint32_t lg0) { return fix_lg_for(used + c + 1u, lg0); }
+
+// pass 0: the rows the deferred ops name and the directory does not hold yet (src/smatrix.c:641-662).  k_prep's creation
+// protocol reserves directory places and 16-cell blocks once per 1024 ops; on 15 M deferred ops that is 3 x 15 000
+// atomics on three words (0.9 ms).  Here a workgroup folds 4096 ops by row id in LDS first, probes once per distinct
+// id and reserves once per 4096 ops.  A refused reservation (directory at its limit) sets ctl->dir_full: the host
+// rebuilds the directory and runs the pass again, exactly as for k_prep.
+constexpr uint32_t FIXR_OPT = 16, FIXR_SLOTS = 8192;
+__global__ __launch_bounds__(256) void k_fix_create(Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint32_t n,
+                                                    const uint32_t* defer, const uint32_t* __restrict__ xs, uint32_t st,
+                                                    uint64_t arena_cap_units, FreeLists fl) {
+  __shared__ uint32_t l_key[FIXR_SLOTS];                            // distinct row ids of the tile (FIX_NONE cannot use the set)
+  __shared__ uint32_t l_cnt[8];                                     // [0] want, [1] reserved ok, [2] won, [3] popped, [4] old stack height
+  __shared__ unsigned long long l_u0;
+  for (uint32_t t0 = blockIdx.x * 256u * FIXR_OPT; t0 < n; t0 += gridDim.x * 256u * FIXR_OPT) {   // block-uniform
+    for (uint32_t i = threadIdx.x; i < FIXR_SLOTS; i += 256) l_key[i] = FIX_NONE;
+    if (threadIdx.x < 8) l_cnt[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t k = 0; k < FIXR_OPT; k++) {
+      const uint32_t t = t0 + k * 256u + threadIdx.x;
+      if (t >= n) continue;
+      const uint32_t X = xs[(size_t)defer[t] * st];
+      if (X == FIX_NONE) continue;                                  // (left to the round loop's prep)
+      uint32_t q = (X * 0x9E3779B1u) >> 19;                         // 13 bits
+      for (;;) {
+        const uint32_t prev = atomicCAS(&l_key[q], FIX_NONE, X);
+        if (prev == FIX_NONE || prev == X) break;
+        q = (q + 1) & (FIXR_SLOTS - 1);
+      }
+    }
+    __syncthreads();
+    // one lane per distinct id: is the row there?  (atomic loads: other workgroups create rows right now)
+    uint32_t mine[FIXR_SLOTS / 256], hh[FIXR_SLOTS / 256], nm = 0;
+    for (uint32_t i = threadIdx.x; i < FIXR_SLOTS; i += 256) {
+      const uint32_t X = l_key[i];
+      if (X == FIX_NONE) continue;
+      uint32_t h = fmix32(X) & dmask;
+      for (;;) {
+        const uint64_t cur = ld_relaxed(reinterpret_cast<uint64_t*>(&dir[h]));
+        if (cur == 0) { mine[nm] = X; hh[nm] = h; nm++; break; }
+        if ((uint32_t)(cur >> 32) == X) break;
+        h = (h + 1) & dmask;
+      }
+    }
+    if (nm) atomicAdd(&l_cnt[0], nm);
+    __syncthreads();
+    if (threadIdx.x == 0 && l_cnt[0]) {
+      const uint32_t before = atomicAdd(&ctl->dir_used, l_cnt[0]);
+      if ((uint64_t)before + l_cnt[0] <= dir_limit) l_cnt[1] = 1;
+      else { atomicSub(&ctl->dir_used, l_cnt[0]); ctl->dir_full = 1; }
+    }
+    __syncthreads();
+    uint32_t wonm = 0, rank[FIXR_SLOTS / 256];
+    if (l_cnt[1])
+      for (uint32_t k = 0; k < nm; k++) {
+        const uint32_t X = mine[k];
+        const uint64_t want = (uint64_t)(META_USED | META_DIRTY | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+        uint32_t h = hh[k];
+        for (;;) {
+          const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[h]), 0ull, (unsigned long long)want);
+          if (prev == 0) { wonm |= 1u << k; rank[k] = atomicAdd(&l_cnt[2], 1u); hh[k] = h; break; }
+          if ((uint32_t)(prev >> 32) == X) break;                  // another workgroup created it
+          uint64_t cur;
+          do {
+            h = (h + 1) & dmask;
+            cur = ld_relaxed(reinterpret_cast<uint64_t*>(&dir[h]));
+          } while (cur != 0 && (uint32_t)(cur >> 32) != X);
+          if (cur != 0) break;
+        }
+      }
+    __syncthreads();
+    if (threadIdx.x == 0 && l_cnt[1]) {
+      const uint32_t n_res = l_cnt[0], n_won = l_cnt[2];
+      if (n_res > n_won) atomicSub(&ctl->dir_used, n_res - n_won);
+      uint32_t got = 0;
+      int32_t top = 0;
+      if (n_won) {
+        top = atomicSub(&ctl->free_cnt[0], (int32_t)n_won);          // retired (zeroed) 16-cell blocks first
+        got = top > 0 ? min((uint32_t)top, n_won) : 0u;
+        if (got < n_won) atomicAdd(&ctl->free_cnt[0], (int32_t)(n_won - got));
+        if (got < n_won)
+          l_u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)(n_won - got));
+      }
+      l_cnt[3] = got;
+      l_cnt[4] = (uint32_t)top;
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nm; k++) {
+      if (!(wonm & (1u << k))) continue;
+      const uint32_t got = l_cnt[3];
+      const uint64_t u = rank[k] < got ? fl.list[0][l_cnt[4] - 1u - rank[k]] : l_u0 + (rank[k] - got);
+      if (u >= arena_cap_units) ctl->arena_oom = 1;                 // the host guarantees this never fires
+      else __hip_atomic_store(&dir[hh[k]].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+
+// pass 1: ops per directory slot; where[t] = the slot of deferred op t, or FIX_NONE for an op the bulk path does not take.
+// A workgroup first folds its 2048 ops by slot in an LDS table (bulk loads name the same row many times in a row:
+// the config-3 stream has 115 consecutive ops per row), then adds each distinct slot's count with ONE global atomic.
+constexpr uint32_t FIXC_OPT = 8, FIXC_SLOTS = 4096;
+__global__ __launch_bounds__(256) void k_fix_count(Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t n, const uint32_t* defer,
+                                                   const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t st,
+                                                   uint32_t* cnt, uint32_t* where, uint32_t* defer_out, uint32_t* touched,
+                                                   uint32_t* pos_of) {
+  // touched[0 .. ctl->n_tasks): the directory slots with pending ops (a slot is listed by whoever raises its count from
+  // 0), pos_of[h] = its place in that list -- everything after this pass works on that list, not on the directory
+  __shared__ uint32_t l_key[FIXC_SLOTS], l_cnt[FIXC_SLOTS];
+  __shared__ uint32_t l_n, l_base, l_first, l_fbase;
+  for (uint32_t t0 = blockIdx.x * 256u * FIXC_OPT; t0 < n; t0 += gridDim.x * 256u * FIXC_OPT) {   // block-uniform
+    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) { l_key[i] = FIX_NONE; l_cnt[i] = 0; }
+    if (threadIdx.x == 0) { l_n = 0; l_first = 0; }
+    __syncthreads();
+    uint32_t jb[FIXC_OPT], rk[FIXC_OPT];
+    uint32_t backm = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < FIXC_OPT; k++) {
+      const uint32_t t = t0 + k * 256u + threadIdx.x;
+      if (t >= n) continue;
+      const uint32_t j = defer[t];
+      jb[k] = j;
+      uint4 sn;
+      DirSlot* d = ys[(size_t)j * st] != 0 ? dir_find(dir, dmask, xs[(size_t)j * st], &sn) : nullptr;
+      if (d && sn.z != 0 && meta_lg(sn.x) <= FIX_MAX_LG) {
+        const uint32_t h = (uint32_t)(d - dir);
+        where[t] = h;
+        uint32_t q = (h * 0x9E3779B1u) >> 20;                       // 12 bits
+        for (;;) {
+          const uint32_t prev = atomicCAS(&l_key[q], FIX_NONE, h);
+          if (prev == FIX_NONE || prev == h) break;
+          q = (q + 1) & (FIXC_SLOTS - 1);
+        }
+        atomicAdd(&l_cnt[q], 1u);
+      } else {
+        where[t] = FIX_NONE;
+        backm |= 1u << k;
+        rk[k] = atomicAdd(&l_n, 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t fh[FIXC_SLOTS / 256], fr[FIXC_SLOTS / 256], nf = 0;     // slots this lane raised from 0: they join the list
+    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256)
+      if (l_cnt[i] && atomicAdd(&cnt[l_key[i]], l_cnt[i]) == 0) { fh[nf] = l_key[i]; fr[nf] = atomicAdd(&l_first, 1u); nf++; }
+    __syncthreads();
+    if (threadIdx.x == 0 && l_n) l_base = atomicAdd(&ctl->n_defer, l_n);
+    if (threadIdx.x == 0 && l_first) l_fbase = atomicAdd(&ctl->n_tasks, l_first);
+    __syncthreads();
+    for (uint32_t k = 0; k < nf; k++) { touched[l_fbase + fr[k]] = fh[k]; pos_of[fh[k]] = l_fbase + fr[k]; }
+#pragma unroll
+    for (uint32_t k = 0; k < FIXC_OPT; k++)
+      if (backm & (1u << k)) defer_out[l_base + rk[k]] = jb[k];
+    __syncthreads();
+  }
+}
+
+// pass 2: per directory slot {ops, units of a new block} -> exclusive scan (three launches: tiles, tile totals, add).
+// A row is ELIGIBLE if its table can end at no more than 2^FIX_MAX_LG cells even if every pending op is a new key;
+// it gets a block of that bound's size class when the bound exceeds its present size.
+constexpr uint32_t SCAN_TILE = 2048;
+__device__ inline uint64_t fix_elem(const DirSlot* dir, const uint32_t* cnt, const uint32_t* touched, uint32_t i, uint32_t nrows,
+                                    uint64_t* wide) {
+  if (i >= nrows) return 0;
+  const uint32_t h = touched[i];
+  const uint32_t c = cnt[h];
+  const DirSlot d = dir[h];
+  const uint32_t lg = meta_lg(d.meta), lgb = fix_bound_lg(d.used, c, lg);
+  if (lgb > FIX_MAX_LG) return (uint64_t)c;                        // ineligible: ops only (they go back to the list)
+  if (lgb == FIX_MAX_LG) *wide = 1;                                // the second k_fix_rows pass has work (benign race: all store 1)
+  return (uint64_t)c | ((uint64_t)(lgb > lg ? (uint32_t)units_of_lg(lgb) : 0u) << 32);
+}
+__global__ __launch_bounds__(256) void k_fix_scan_tiles(const Ctl* ctl, const DirSlot* dir, const uint32_t* cnt, const uint32_t* touched,
+                                                        uint64_t* excl, uint64_t* tile_sum, uint64_t* wide) {
+  __shared__ uint64_t l_w[4];
+  const uint32_t dir_size = aload(&ctl->n_tasks);                  // (the list's length; the name is kept for the code below)
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8u;
+  uint64_t v[8], run = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { v[k] = fix_elem(dir, cnt, touched, base + k, dir_size, wide); run += v[k]; }
+  // both halves stay below 2^32 over the whole directory (ops < 2^32, units < 2^32): the packed sums never carry across
+  uint64_t inc = run;
+  const uint32_t lane = __lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(inc >> 32), o) << 32) | (uint32_t)__shfl_up((int)inc, o);
+    if (lane >= (uint32_t)o) inc += up;
+  }
+  if (lane == 63) l_w[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint64_t before = 0;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) before += l_w[w];
+  uint64_t e = before + inc - run;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (base + k < dir_size) excl[base + k] = e;
+    e += v[k];
+  }
+  if (threadIdx.x == 255) tile_sum[blockIdx.x] = before + inc;
+}
+__global__ __launch_bounds__(1024) void k_fix_scan_tops(uint64_t* tile_sum, uint32_t ntiles, uint64_t* total) {
+  __shared__ uint64_t l_w[16];
+  __shared__ uint64_t l_run;
+  if (threadIdx.x == 0) l_run = 0;
+  __syncthreads();
+  const uint32_t lane = __lane_id(), w = threadIdx.x >> 6;
+  for (uint32_t t0 = 0; t0 < ntiles; t0 += 1024) {                  // block-uniform
+    const uint32_t t = t0 + threadIdx.x;
+    const uint64_t v = t < ntiles ? tile_sum[t] : 0;
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(inc >> 32), o) << 32) | (uint32_t)__shfl_up((int)inc, o);
+      if (lane >= (uint32_t)o) inc += up;
+    }
+    if (lane == 63) l_w[w] = inc;
+    __syncthreads();
+    uint64_t before = l_run;
+    for (uint32_t k = 0; k < w; k++) before += l_w[k];
+    if (t < ntiles) tile_sum[t] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) l_run = before + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = l_run;
+}
+__global__ __launch_bounds__(256) void k_fix_scan_add(const Ctl* ctl, uint64_t* excl, const uint64_t* tile_sum) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < aload(&ctl->n_tasks)) excl[i] += tile_sum[i / SCAN_TILE];
+}
+
+// pass 3: the op indices, row by row -- the same LDS fold: a workgroup reserves its share of a row's range once
+__global__ __launch_bounds__(256) void k_fix_scatter(uint32_t n, const uint32_t* defer, const uint32_t* where,
+                                                     const uint64_t* excl, const uint32_t* pos_of, uint32_t* cursor, uint32_t* grouped) {
+  __shared__ uint32_t l_key[FIXC_SLOTS], l_cnt[FIXC_SLOTS];
+  for (uint32_t t0 = blockIdx.x * 256u * FIXC_OPT; t0 < n; t0 += gridDim.x * 256u * FIXC_OPT) {   // block-uniform
+    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) { l_key[i] = FIX_NONE; l_cnt[i] = 0; }
+    __syncthreads();
+    uint32_t hb[FIXC_OPT], qb[FIXC_OPT], rk[FIXC_OPT];
+#pragma unroll
+    for (uint32_t k = 0; k < FIXC_OPT; k++) {
+      const uint32_t t = t0 + k * 256u + threadIdx.x;
+      hb[k] = t < n ? where[t] : FIX_NONE;
+      if (hb[k] == FIX_NONE) continue;
+      uint32_t q = (hb[k] * 0x9E3779B1u) >> 20;
+      for (;;) {
+        const uint32_t prev = atomicCAS(&l_key[q], FIX_NONE, hb[k]);
+        if (prev == FIX_NONE || prev == hb[k]) break;
+        q = (q + 1) & (FIXC_SLOTS - 1);
+      }
+      qb[k] = q;
+      rk[k] = atomicAdd(&l_cnt[q], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256)
+      if (l_cnt[i]) l_cnt[i] = (uint32_t)excl[pos_of[l_key[i]]] + atomicAdd(&cursor[l_key[i]], l_cnt[i]);   // -> this workgroup's first position
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < FIXC_OPT; k++) {
+      if (hb[k] == FIX_NONE) continue;
+      grouped[l_cnt[qb[k]] + rk[k]] = defer[t0 + k * 256u + threadIdx.x];
+    }
+    __syncthreads();
+  }
+}
+
+// one lane, on the LDS table: the reference's probe (src/smatrix.c:363-380)
+__device__ inline uint32_t fix_probe(const uint64_t* T, uint32_t mask, uint32_t key) {
+  uint32_t i = key & mask;
+  while (cell_key(T[i]) != key && T[i] != 0) i = (i + 1) & mask;
+  return i;
+}
+
+// pass 4: one wave per row with pending ops, the row's table in LDS from the first op to the last.  64 ops at a time:
+// every lane probes for its key; hits and as many new keys as the threshold admits are applied together (LDS CAS
+// claims + LDS adds = some order of those ops in which every insert saw used <= size/2); if new keys are left over the
+// table is doubled -- priority probing on old slot indices (LDS atomicMin, as in k_grow_lds) gives the layout of the
+// reference's re-insertion in old slot order; a table that holds a key twice (quirk fallout) is redone by one lane
+// exactly as smatrix_rmap_resize does it -- and the rest goes on.  (A first version ran the reference's code with one
+// lane per row: 6.0 ms per 15 M-op batch; one op at a time with wave-wide probing: 3.4 ms.)
+// Two instantiations share the rows: MAXLG = FIX_MAX_LG - 1 takes every row that can end at <= 256 cells (5 KB of LDS
+// per wave: 28 waves per CU) and hands the ineligible ones back; MAXLG = FIX_MAX_LG takes the rows that may reach 512.
+template <int OP, uint32_t MAXLG>
+__global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
+    Ctl* ctl, DirSlot* dir, const uint32_t* touched, uint8_t* arena, uint32_t* cnt, uint32_t* cursor, const uint64_t* excl,
+    const uint32_t* grouped, const uint32_t* __restrict__ ys, const uint32_t* __restrict__ vs, uint32_t st,
+    uint32_t* __restrict__ out, uint32_t* defer_out, uint64_t new_base0, FreeLists fl) {
+  static_assert(OP == OP_INCR || OP == OP_DECR, "the bulk path takes the commutative writers");
+  static_assert(MAXLG == FIX_MAX_LG || MAXLG + 1 == FIX_MAX_LG, "two passes");
+  constexpr uint32_t SMAX = 1u << MAXLG;
+  __shared__ uint64_t l_tab[FIX_WAVES][2][SMAX];
+  __shared__ uint32_t l_idx[FIX_WAVES][SMAX];                       // resize: old slot index per new slot
+  __shared__ uint32_t l_ret[FIX_WAVES][64], l_rcls[FIX_WAVES][64];  // blocks this wave has retired: base, size class
+  __shared__ uint32_t l_nret[FIX_WAVES];
+  const uint32_t lane = __lane_id(), w = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * FIX_WAVES + w, nwaves = gridDim.x * FIX_WAVES;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  if (lane == 0) l_nret[w] = 0;
+  auto wsync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // retired 16*2^c-cell blocks go back to their size class's stack (zeroed); one list reservation per 64 of them
+  auto flush_retired = [&]() {
+    const uint32_t nr = l_nret[w];
+    for (uint32_t c = 0; c <= MAXLG - ROW_FIRST_LG; c++) {
+      const bool mine = lane < nr && l_rcls[w][lane] == c;
+      const uint64_t m = __ballot(mine);
+      if (!m) continue;
+      const int lead = __ffsll((unsigned long long)m) - 1;
+      uint32_t at = 0;
+      if ((int)lane == lead) at = (uint32_t)atomicAdd(&ctl->free_cnt[c], (int32_t)__popcll(m));
+      at = (uint32_t)__shfl((int)at, lead);
+      if (mine) fl.list[c][at + (uint32_t)__popcll(m & lt)] = l_ret[w][lane];
+    }
+    wsync();
+    if (lane == 0) l_nret[w] = 0;
+    wsync();
+  };
+  const uint32_t nrows = aload(&ctl->n_tasks);
+  for (uint32_t ri = wave; ri < nrows; ri += nwaves) {                                    // wave-uniform
+    {
+      const uint32_t h = touched[ri];
+      const uint32_t c = cnt[h];
+      if (c == 0) continue;                                         // the other pass has taken it
+      const DirSlot d = dir[h];
+      const uint64_t e = excl[ri];
+      const uint32_t p0 = (uint32_t)e;
+      const uint32_t lg0 = meta_lg(d.meta);
+      const uint32_t lgb = fix_bound_lg(d.used, c, lg0);
+      if (MAXLG == FIX_MAX_LG ? lgb != FIX_MAX_LG : lgb == FIX_MAX_LG) continue;         // the other pass's row
+      if (lgb > FIX_MAX_LG || (d.meta & (META_GROW | META_REBAL))) {
+        // not for this path: the row's ops go back to the round loop
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&ctl->n_defer, c);
+        at = (uint32_t)__shfl((int)at, 0);
+        for (uint32_t i = lane; i < c; i += 64) defer_out[at + i] = grouped[p0 + i];
+        wsync();
+        if (lane == 0) { cnt[h] = 0; cursor[h] = 0; }
+        continue;
+      }
+      wsync();
+      if (lane == 0) { cnt[h] = 0; cursor[h] = 0; }                 // taken; and both arrays are all-zero again for the next batch
+      uint32_t cur = 0;                                             // which of the two LDS tables is live
+      uint64_t* cells = row_cells(arena, d.base);
+      uint32_t lg = lg0, used = d.used;
+      for (uint32_t i = lane; i < (1u << lg); i += 64) l_tab[w][0][i] = cells[i];
+      wsync();
+      for (uint32_t c0 = 0; c0 < c; c0 += 64) {
+        // this lane's op of the chunk; its result ends up in `res`
+        uint32_t j = 0, Yl = 0, Vl = 0, res = 0;
+        if (c0 + lane < c) {
+          j = grouped[p0 + c0 + lane];
+          Yl = ys[(size_t)j * st];
+          Vl = vs[(size_t)j * st];
+        }
+        // FILL -> GROW -> FILL: all hits of the chunk and as many of its new keys as the reference's threshold leaves
+        // room for go in together (LDS CAS claims, LDS adds: some order of these ops -- each insert at a moment when
+        // used <= size/2 held); when keys are left and the room is gone the table is doubled and the rest goes on
+        bool pending = c0 + lane < c;
+        while (__any(pending)) {                                    // wave-uniform
+          uint64_t* T = l_tab[w][cur];
+          const uint32_t S = 1u << lg, mask = S - 1u;
+          bool absent = false;
+          uint32_t slot = Yl & mask;
+          bool stuck = false;                                       // no empty cell at all (only a foreign, over-full table): resize first
+          if (pending)
+            for (uint32_t steps = 0;; steps++) {                    // smatrix_rmap_probe, src/smatrix.c:363-380
+              const uint64_t cc = T[slot];
+              if (cell_key(cc) == Yl) break;
+              if (cc == 0) { absent = true; break; }
+              if (steps > mask) { absent = true; stuck = true; break; }
+              slot = (slot + 1) & mask;
+            }
+          const uint32_t room = used <= S / 2u ? S / 2u + 1u - used : 0u;   // inserts the threshold still admits (:346)
+          const uint64_t ma = __ballot(pending && absent);
+          const bool go = pending && !stuck && (!absent || (uint32_t)__popcll(ma & lt) < room);
+          bool inserted = false;
+          if (go) {
+            while (absent) {
+              const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&T[slot]), 0ull,
+                                              (unsigned long long)pack_cell(Yl, 0));      // :354-356
+              if (prev == 0) { inserted = true; break; }
+              for (;;) {                                            // the slot went to another lane: look again from here
+                const uint64_t cc = T[slot];
+                if (cell_key(cc) == Yl) { absent = false; break; }  // ... to a lane with the same key
+                if (cc == 0) break;
+                slot = (slot + 1) & mask;
+              }
+            }
+            uint32_t* vp = reinterpret_cast<uint32_t*>(&T[slot]) + 1;
+            res = OP == OP_INCR ? atomicAdd(vp, Vl) + Vl : atomicSub(vp, Vl) - Vl;        // :241 / :252
+            pending = false;
+          }
+          used += (uint32_t)__popcll(__ballot(inserted));
+          wsync();
+          if (!__any(go) && __any(pending)) {
+            // ---- smatrix_rmap_resize (src/smatrix.c:383-416): S -> 2S, old slot order
+            uint64_t* N = l_tab[w][cur ^ 1u];
+            const uint32_t nmask = 2u * S - 1u;
+            for (uint32_t q = lane; q <= nmask; q += 64) l_idx[w][q] = FIX_NONE;
+            wsync();
+            uint32_t moved = 0;
+            for (uint32_t p = lane; p < S; p += 64) {
+              const uint64_t cc = T[p];
+              if (cc == 0) continue;
+              moved++;
+              uint32_t carry = p, i2 = cell_key(cc) & nmask;
+              for (;;) {
+                const uint32_t prev = atomicMin(&l_idx[w][i2], carry);
+                if (prev == FIX_NONE) break;
+                if (prev > carry) carry = prev;                     // evicted a later cell: carry it onward
+                i2 = (i2 + 1) & nmask;
+              }
+            }
+            wsync();
+            bool dup = false;                                       // a key that a probe from its home finds elsewhere first
+            for (uint32_t q = lane; q <= nmask; q += 64) {
+              const uint32_t r = l_idx[w][q];
+              if (r == FIX_NONE) continue;
+              const uint32_t key = cell_key(T[r]);
+              uint32_t i2 = key & nmask;
+              while (i2 != q) {
+                const uint32_t r2 = l_idx[w][i2];
+                if (r2 == FIX_NONE || cell_key(T[r2]) == key) break;
+                i2 = (i2 + 1) & nmask;
+              }
+              if (i2 != q) dup = true;
+            }
+            if (!__any(dup)) {
+              for (uint32_t q = lane; q <= nmask; q += 64) {
+                const uint32_t r = l_idx[w][q];
+                N[q] = r == FIX_NONE ? 0ull : T[r];
+              }
+              for (int o = 32; o > 0; o >>= 1) moved += (uint32_t)__shfl_xor((int)moved, o);
+              used = moved;
+            } else {
+              uint32_t nu = 0;
+              if (lane == 0) {                                      // the reference's way, one cell after the other
+                for (uint32_t q = 0; q <= nmask; q++) N[q] = 0;
+                for (uint32_t q = 0; q <= mask; q++) {
+                  const uint64_t cc = T[q];
+                  if (cc == 0) continue;
+                  const uint32_t z = fix_probe(N, nmask, cell_key(cc));
+                  if (cell_key(N[z]) == 0 || cell_key(N[z]) != cell_key(cc)) nu++;       // :353-354
+                  N[z] = cc;
+                }
+              }
+              used = (uint32_t)__shfl((int)nu, 0);
+            }
+            wsync();
+            cur ^= 1u;
+            lg++;
+          }
+        }
+        if (c0 + lane < c) out[j] = res;
+      }
+      uint64_t* T = l_tab[w][cur];
+      uint64_t* dst = cells;
+      if (lg != lg0) {
+        dst = row_cells(arena, (uint32_t)(new_base0 + (e >> 32)));
+        for (uint32_t i = lane; i < (1u << lg0); i += 64) cells[i] = 0;                   // retired blocks are all-empty
+        if (lane == 0) {
+          l_ret[w][l_nret[w]] = d.base;
+          l_rcls[w][l_nret[w]] = lg0 - ROW_FIRST_LG;
+          l_nret[w]++;
+        }
+      }
+      for (uint32_t i = lane; i < (1u << lg); i += 64) dst[i] = T[i];
+      if (lane == 0) {
+        DirSlot nd;
+        nd.meta = META_USED | META_DIRTY | (lg << META_LG_SHIFT);
+        nd.x = d.x;
+        nd.base = lg != lg0 ? (uint32_t)(new_base0 + (e >> 32)) : d.base;
+        nd.used = used;
+        dir[h] = nd;
+      }
+      wsync();
+      if (l_nret[w] == 64) flush_retired();
+    }
+  }
+  if (l_nret[w]) flush_retired();
 }
 
 // ---- growth -------------------------------------------------------------------

@@ -350,6 +350,13 @@ struct Matrix {
   bool file_fsync = false;              // SMATRIX_FSYNC=1: fsync between the row blocks and the CMAP entries, and after
   uint64_t flush_every = 0;             // SMATRIX_FLUSH_EVERY=N: checkpoint the file after every N write batches
   uint64_t dbg_after = 0;               // SMATRIX_DBG_AFTER: batch number from which a measurement build's debug mode applies
+  // the bulk path (k_fix_*): taken in round 0 when the previous write batch deferred a large share of its ops
+  bool bulk_enabled = true;             // SMATRIX_BULK=0 switches it off
+  bool expect_bulk = true;              // an empty matrix creates its rows: expect it
+  uint32_t fix_min = 1u << 18;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN)
+  DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped;
+  uint32_t fx_dir_size = 0;             // directory size fx_cnt / fx_cur / fx_pos were laid out (and zeroed) for
+  DevBuf<uint64_t> fx_excl, fx_tiles;
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
 };
 
@@ -533,6 +540,79 @@ void grow_rows(Matrix* m, hipStream_t s) {
   m->st.rows_grown += nt;
 }
 
+// The bulk path of a write batch (smx_kernels.hpp "the bulk path"): `nd` deferred ops in `dl`; returns how many were
+// handed back (in `dl_out`) for the round loop.
+template <int OP>
+uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out, const uint32_t* x, const uint32_t* y,
+                    const uint32_t* v, uint32_t* out, hipStream_t s) {
+  // 1. the rows (directory growth included) -- prep without its growth decisions
+  for (int tries = 0;; tries++) {
+    if (tries > 40) smx_die("bulk path: the directory does not take the batch's rows");
+    const uint32_t dir_limit = m->dir_size / 2;
+    const uint32_t room = dir_limit > m->dir_used ? dir_limit - m->dir_used : 0;
+    ensure_arena_free(m, std::min<uint64_t>(nd, room), s);
+    ctl_reset_round(m, s);
+    hipLaunchKernelGGL(k_fix_create, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXR_OPT), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir,
+                       m->dir_size - 1, dir_limit, nd, dl, x, m->in_stride, (uint64_t)(m->arena.mapped / UNIT_BYTES), m->fl);
+    HIP_OK(hipGetLastError());
+    ctl_read(m, s);
+    if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
+    const bool full = m->h_ctl->dir_full != 0;
+    if (full) grow_directory(m, 4, s);
+    else if ((uint64_t)m->dir_used * 2 >= m->dir_size) grow_directory(m, 2, s);
+    if (!full) break;
+  }
+  // 2. ops per row, scan, scatter.  cnt / cursor are indexed by directory slot and ALL ZERO between batches (k_fix_rows
+  //    clears what it takes), so nothing here costs O(directory): the passes run over the batch's ops and its touched rows
+  const uint32_t ds = m->dir_size;
+  if (m->fx_dir_size != ds) {
+    m->fx_cnt.need(ds); m->fx_cur.need(ds); m->fx_pos.need(ds);
+    HIP_OK(hipMemsetAsync(m->fx_cnt.p, 0, (size_t)ds * 4, s));
+    HIP_OK(hipMemsetAsync(m->fx_cur.p, 0, (size_t)ds * 4, s));
+    m->fx_dir_size = ds;
+  }
+  const uint32_t rows_max = (uint32_t)std::min<uint64_t>(nd, m->dir_used);          // touched rows at most
+  const uint32_t ntiles = (rows_max + SCAN_TILE - 1) / SCAN_TILE;
+  m->fx_touched.need(std::max<uint32_t>(rows_max, 1)); m->fx_excl.need(std::max<uint32_t>(rows_max, 1)); m->fx_tiles.need(ntiles + 2);
+  m->fx_where.need(nd); m->fx_grouped.need(nd);
+  ctl_reset_round(m, s);                                       // n_defer: what is handed back; n_tasks: rows touched
+  hipLaunchKernelGGL(k_fix_count, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXC_OPT), 8192)), dim3(256), 0, s, m->d_ctl, m->d_dir, ds - 1, nd,
+                     dl, x, y, m->in_stride, m->fx_cnt.p, m->fx_where.p, dl_out, m->fx_touched.p, m->fx_pos.p);
+  HIP_OK(hipMemsetAsync(m->fx_tiles.p + ntiles, 0, 16, s));     // {total, "rows of the wide class exist"}
+  hipLaunchKernelGGL(k_fix_scan_tiles, dim3(std::max(ntiles, 1u)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->fx_cnt.p, m->fx_touched.p,
+                     m->fx_excl.p, m->fx_tiles.p, m->fx_tiles.p + ntiles + 1);
+  hipLaunchKernelGGL(k_fix_scan_tops, dim3(1), dim3(1024), 0, s, m->fx_tiles.p, ntiles, m->fx_tiles.p + ntiles);
+  hipLaunchKernelGGL(k_fix_scan_add, dim3(blocks_for(std::max<uint32_t>(rows_max, 1))), dim3(256), 0, s, m->d_ctl, m->fx_excl.p, m->fx_tiles.p);
+  hipLaunchKernelGGL(k_fix_scatter, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXC_OPT), 8192)), dim3(256), 0, s, nd, dl, m->fx_where.p, m->fx_excl.p,
+                     m->fx_pos.p, m->fx_cur.p, m->fx_grouped.p);
+  HIP_OK(hipGetLastError());
+  uint64_t tw[2] = {0, 0};
+  HIP_OK(hipMemcpyAsync(tw, m->fx_tiles.p + ntiles, 16, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  const uint64_t units = tw[0] >> 32;
+  // 3. the new blocks: ONE reservation for all rows (their offsets are the scan's upper halves)
+  ensure_arena_free(m, units, s);
+  if (m->arena_next + units >= (1ull << 32)) smx_die("row arena exhausted");
+  const uint64_t new_base0 = m->arena_next;
+  const uint64_t rows_bound = std::min<uint64_t>(nd, m->dir_used);
+  for (uint32_t c = 0; c <= FIX_MAX_LG - ROW_FIRST_LG; c++) ensure_free_cap(m, c, rows_bound, s);
+  const dim3 fgrid(std::min<uint32_t>((rows_max + FIX_WAVES - 1) / FIX_WAVES, 8192));
+  hipLaunchKernelGGL((k_fix_rows<OP, FIX_MAX_LG - 1>), fgrid, dim3(64 * FIX_WAVES), 0, s,
+                     m->d_ctl, m->d_dir, m->fx_touched.p, m->arena.base, m->fx_cnt.p, m->fx_cur.p, m->fx_excl.p, m->fx_grouped.p, y, v,
+                     m->in_stride, out, dl_out, new_base0, m->fl);
+  if (tw[1])
+    hipLaunchKernelGGL((k_fix_rows<OP, FIX_MAX_LG>), fgrid, dim3(64 * FIX_WAVES), 0, s,
+                     m->d_ctl, m->d_dir, m->fx_touched.p, m->arena.base, m->fx_cnt.p, m->fx_cur.p, m->fx_excl.p, m->fx_grouped.p, y, v,
+                     m->in_stride, out, dl_out, new_base0, m->fl);
+  HIP_OK(hipGetLastError());
+  const uint64_t next = new_base0 + units;
+  HIP_OK(hipMemcpyAsync(&m->d_ctl->arena_next, &next, 8, hipMemcpyHostToDevice, s));
+  ctl_read(m, s);
+  m->st.bulk_rounds++;
+  m->st.bulk_ops += nd - m->h_ctl->n_defer;
+  return m->h_ctl->n_defer;
+}
+
 // The write-batch round loop (device pointers).
 void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t* y,
                const uint32_t* v, uint32_t* out, hipStream_t s) {
@@ -567,10 +647,35 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
+    if (round == 0 && m->bulk_enabled && m->expect_bulk && (op == OP_INCR || op == OP_DECR) && n >= m->fix_min) {
+      // the previous batch deferred a large share of its ops (bulk load, young matrix): look at this one's count
+      // before prep -- one extra read-back, only in this regime -- and group a large remainder by row instead of
+      // walking it through a round per doubling
+      ctl_read(m, s);
+      if (timed0) { account_kernel_time(m, op, n); timed0 = false; }
+      const uint32_t nd0 = m->h_ctl->n_defer;
+      m->expect_bulk = (uint64_t)nd0 * 8 >= n;
+      if (nd0 >= m->fix_min) {
+        m->st.rounds++;
+        m->st.deferred_ops += nd0;
+        m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
+        uint32_t* dl2 = m->defer[1].p;
+        const uint32_t nd2 = op == OP_INCR ? run_bulk_t<OP_INCR>(m, nd0, dl, dl2, x, y, v, out, s)
+                                           : run_bulk_t<OP_DECR>(m, nd0, dl, dl2, x, y, v, out, s);
+        if (m->trace_rounds)
+          fprintf(stderr, "[smatrix] batch %llu bulk path: %u deferred ops grouped by row, %u handed back, rows=%u\n",
+                  (unsigned long long)m->st.batches, nd0, nd2, m->dir_used);
+        if (nd2 == 0) break;
+        idx = dl2;                       // what was handed back sits in defer[1]: the next round must write defer[0],
+        cur_n = nd2;                     // so it is numbered 2
+        round++;
+        continue;
+      }
+    }
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                        (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
-                       m->rebal.p, m->fl, m->in_stride);
+                       m->rebal.p, m->fl, m->in_stride, 0u);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
@@ -588,6 +693,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     }
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = m->h_ctl->n_defer;
+    if (round == 0) m->expect_bulk = (uint64_t)nd * 8 >= n;
     if (nd == 0) break;
     if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
@@ -745,6 +851,8 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
   m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* a = getenv("SMATRIX_DBG_AFTER")) m->dbg_after = strtoull(a, nullptr, 10);
+  if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
+  if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_FSYNC")) m->file_fsync = *a == '1';
   if (const char* a = getenv("SMATRIX_FLUSH_EVERY")) m->flush_every = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
@@ -789,6 +897,7 @@ void smatrix_close(smatrix_t* self) {
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
+      m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);

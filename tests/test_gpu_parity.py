@@ -344,6 +344,43 @@ def test_dense_ids_cooperative_probe_all_ops(G, oracle_mod):
     g.close(); o.close(); gen.close()
 
 
+def test_bulk_path_groups_deferred_ops_by_row(G, oracle_mod, monkeypatch):
+    """The bulk path (k_fix_*: deferred ops grouped by row, one wave per row running the reference's insert / resize
+    sequence on an LDS table) forced onto small batches (SMATRIX_BULK_MIN=1): new rows, rows that already hold cells,
+    duplicate keys inside a batch, decr below zero, y = 0 ops and rows that outgrow the path's 512-cell limit (both
+    handed back to the round loop) -- values, per-key return multisets, row sizes and rowlens are the oracle's and the
+    tables are valid probe layouts."""
+    monkeypatch.setenv("SMATRIX_BULK_MIN", "1")
+    rng = np.random.default_rng(41)
+    g, o = G(), oracle_mod.Oracle()
+    for rnd, (op, n, nx, ny) in enumerate(((2, 40000, 3000, 1 << 20), (2, 60000, 3500, 1 << 20), (3, 30000, 3500, 1 << 20),
+                                           (2, 200000, 60000, 50), (2, 90000, 200, 1 << 16), (3, 5000, 100000, 7))):
+        x = rng.integers(0, nx, n, dtype=np.uint32)
+        y = rng.integers(0 if rnd == 1 else 1, ny, n, dtype=np.uint32)
+        v = ((x * 3 + y) % 4 + 1).astype(np.uint32)               # one value per key: order-free return multisets
+        if rnd == 1:
+            ok = y != 0                                            # y = 0 is order dependent inside a batch: keep those ops apart
+            g.apply(op, x[~ok], y[~ok], v[~ok]); o.apply(op, x[~ok], y[~ok], v[~ok])
+            x, y, v = x[ok], y[ok], v[ok]
+        a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
+        ka, kb = per_key_sorted(x, y, a), per_key_sorted(x, y, b)
+        assert (ka[1] == kb[1]).all(), rnd
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rnd
+    st = g.stats()
+    assert st["bulk_rounds"] >= 4 and st["bulk_ops"] > 100000, st
+    rows = o.list_rows()
+    assert st["rows"] == rows.size
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    state_equal(g, o, rows.tolist()[:300] + rows.tolist()[-50:], exact_layout=False)
+    # a row fed in ONE op per batch takes the same path and must then be byte-identical (a list of one op has one order)
+    for k in range(1, 200):
+        for m_ in (g, o):
+            m_.apply(2, np.array([4000000], np.uint32), np.array([k * 16 + 5], np.uint32), np.array([k], np.uint32))
+    assert g.row_info(4000000) == o.row_info(4000000)
+    assert (np.asarray(g.row_slots(4000000)) == np.asarray(o.row_slots(4000000))).all()
+    g.close(); o.close()
+
+
 def test_threads_on_one_handle(G):
     """README.md:113,120 of the reference: all data calls are thread-safe on one handle"""
     m = G()
