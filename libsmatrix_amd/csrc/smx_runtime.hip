@@ -340,6 +340,9 @@ struct Matrix {
   bool profile = false;
   bool trace_rounds = false;            // SMATRIX_TRACE_ROUNDS=1: one stderr line per round
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool grow_fork = true;                // SMATRIX_GROW_FORK=0: everything of a growth round on the caller's stream (see grow_rows)
+  hipStream_t helper = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   std::string fname;
   bool dirty = false;                   // file mode: something changed since the file was loaded / last written
@@ -501,6 +504,12 @@ void grow_rows(Matrix* m, hipStream_t s) {
                      m->d_ctl, m->tasks.p, cap_units, m->fl);
   const uint32_t* nk = m->h_ctl->n_kind;
   const uint32_t n_chunked = nk[GROW_CHUNKED];
+  // the chunked passes of the large rows touch other rows than the in-LDS rehashes: they run on a helper stream beside
+  // them, from the plan on (non-blocking stream + events: the caller's stream may be the legacy default stream, which a
+  // blocking helper would serialise with -- round 1's attempt with plain streams was erratic).  Same box, 3 runs each:
+  // 2.72 -> 2.65 ms per config-2 step.  SMATRIX_GROW_FORK=0 keeps everything on the caller's stream.
+  const bool fork = m->grow_fork && n_chunked && (nk[0] || nk[1] || nk[2]);
+  if (fork) HIP_OK(hipEventRecord(m->ev_fork, s));
   if (nk[0])
     hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), 16u << GROW_LG0, s,
                        m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base);
@@ -511,17 +520,25 @@ void grow_rows(Matrix* m, hipStream_t s) {
     hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), 16u << GROW_LG2, s,
                        m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base);
   const uint64_t oc_bound = (uint64_t)n_chunked + gu / 8, nc_bound = (uint64_t)n_chunked + gu / 4;
+  hipStream_t sc = s;
+  if (fork) {
+    HIP_OK(hipStreamWaitEvent(m->helper, m->ev_fork, 0));
+    sc = m->helper;
+  }
   if (n_chunked) {
     hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)nt * 64), 2048)),
-                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->map_new.p);
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->map_new.p);
     hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
     hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
-                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
-  }
-  if (n_chunked)
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
     hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                       dim3(256), 0, s, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+  }
+  if (fork) {
+    HIP_OK(hipEventRecord(m->ev_join, sc));
+    HIP_OK(hipStreamWaitEvent(s, m->ev_join, 0));
+  }
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
   HIP_OK(hipGetLastError());
@@ -839,6 +856,12 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
   HIP_OK(hipEventCreate(&m->ev0));
   HIP_OK(hipEventCreate(&m->ev1));
+  if (const char* a = getenv("SMATRIX_GROW_FORK")) m->grow_fork = *a != '0';
+  if (m->grow_fork) {
+    HIP_OK(hipStreamCreateWithFlags(&m->helper, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  }
   m->dir_size = 65536;                               // SMATRIX_CMAP_INITIAL_SIZE, src/smatrix.h:24
   HIP_OK(hipMalloc(&m->d_dir, (size_t)m->dir_size * sizeof(DirSlot)));
   zero_async(m->d_dir, (size_t)m->dir_size * sizeof(DirSlot), m->stream);
@@ -902,6 +925,9 @@ void smatrix_close(smatrix_t* self) {
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
+      if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+      if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+      if (m->helper) (void)hipStreamDestroy(m->helper);
       if (m->stream) (void)hipStreamDestroy(m->stream);
       clk.lap("buffers freed");
     }

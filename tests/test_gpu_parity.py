@@ -750,11 +750,16 @@ def test_sharded_pipeline_matches_direct():
     assert p.returncode == 0 and "SHARDED_PIPELINE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
-def test_hypothesis_small_sequences_vs_oracle(G, oracle_mod):
+@pytest.mark.parametrize("bulk_min", [None, "1"])
+def test_hypothesis_small_sequences_vs_oracle(G, oracle_mod, monkeypatch, bulk_min):
     """property test: arbitrary short programs of batches over a tiny, collision-heavy id space (y = 0,
     value 0, wrap-around, duplicate keys, repeated growth) -- after every batch all cells, rowlens and row
-    sizes equal the oracle's; batches of one op kind are applied to both in the same index order"""
+    sizes equal the oracle's; batches of one op kind are applied to both in the same index order.
+    Second run: every incr/decr batch is forced through the bulk path (SMATRIX_BULK_MIN=1), whose per-row kernel
+    then meets the quirk rows: (0,v) cells, keys held twice after a chain cut, resizes that merge them."""
     from hypothesis import given, settings, strategies as st, HealthCheck
+    if bulk_min:
+        monkeypatch.setenv("SMATRIX_BULK_MIN", bulk_min)
 
     ids = st.sampled_from([0, 1, 2, 3, 16, 17, 32, 48, 64, 5, 21, 0xFFFFFFFF, 0x80000000])
     vals = st.sampled_from([0, 1, 2, 7, 0xFFFFFFFF])
