@@ -468,6 +468,8 @@ def main():
                     help="test rig: every rank uses cuda:0 and the exchange is staged through the host (gloo)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="route through ShardedMatrix even with one rank (exercises the exchange path)")
+    ap.add_argument("--split-get", action="store_true",
+                    help="sharded path: route the get batch on its own (two partitions and record exchanges per step, round 1's form)")
     ap.add_argument("--c-router", action="store_true",
                     help="sharded path through the C library's own router (smatrix_shard_apply_then_get_dev: RCCL send/recv "
                          "issued by the library, one partition + one record exchange per incr+get step)")
@@ -568,7 +570,23 @@ def main():
     READY = True       # the batches were generated before the timed region: route() need not wait for the compute stream
     lagging = []       # handles whose results the compute stream has not been told to wait for yet
 
+    def step_fused(s):
+        # ONE partition + ONE record exchange per step: the owner applies incr, then get on the records it holds
+        # (ShardedMatrix.apply_routed_get); the records of step s+1 travel under the kernels of step s
+        f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones, READY)
+        h = f_i.result()
+        m.apply_routed(h)
+        if s + 1 < total_steps and s + 1 != args.warmup:           # never across the timing fence
+            pending[s + 1] = comm.submit(m.route, OP_INCR, xs[s + 1], ys[s + 1], ones, READY)
+        m.apply_routed_get(h)
+        comm.submit(m.finish, h, out_i, out_g).result()
+        for hh in lagging:
+            m.wait(hh)
+        lagging[:] = [h]
+
     def step_threaded(s):
+        if not args.split_get:
+            return step_fused(s)
         f_i = pending.pop(s, None) or comm.submit(m.route, OP_INCR, xs[s], ys[s], ones, READY)
         f_g = comm.submit(m.route, OP_GET, xs[s], ys[s], None, READY)           # travels under the incr kernels of s
         h_i = f_i.result()

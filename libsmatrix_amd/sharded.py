@@ -518,7 +518,23 @@ class ShardedMatrix:
             self.shard.apply(h.op, h.xr, h.yr, h.vr, h.outr)
         h.ev_applied = torch.cuda.current_stream().record_event() if h.ev_routed is not None else None
 
-    def finish(self, h, out):
+    def apply_routed_get(self, h):
+        """a get on the SAME keys right behind the write of apply_routed(h) -- the benchmark's step (incr batch, then get
+        batch, src/smatrix_benchmark.c:226-230) with ONE partition and ONE exchange of the op records: the owner reads
+        {x, y} of the records it already holds.  finish(h, out, out_get) then returns both result sets."""
+        assert h.op != OP_GET
+        dev = h.outr.device
+        h.outg = torch.empty(h.outr.numel(), dtype=h.outr.dtype, device=dev)
+        if h.ev_routed is not None:
+            h.outg.record_stream(torch.cuda.current_stream())
+        if h.pr is not None:
+            self.shard.apply_packed(OP_GET, h.pr, h.outg)         # width-3 records: the get kernel skips the value word
+        else:
+            self.shard.apply(OP_GET, h.xr, h.yr, None, h.outg)
+        h.ev_applied = torch.cuda.current_stream().record_event() if h.ev_routed is not None else None
+        self.exchanged_ops += h.outg.numel()
+
+    def finish(self, h, out, out_get=None):
         comm = self._comm(out)
         ctx = torch.cuda.stream(comm) if comm is not None else _null_ctx()
         with ctx:
@@ -528,8 +544,15 @@ class ShardedMatrix:
             back = torch.empty(h.n, dtype=out.dtype, device=out.device)
             self._a2a(back, h.outr, h.counts, h.rcounts)
             self.part.gather(back, h.perm, out)
-            h.ev_done = comm.record_event() if comm is not None else None
             h.keep = h.keep + (back,)
+            if out_get is not None:
+                if comm is not None:
+                    out_get.record_stream(comm)
+                back2 = torch.empty(h.n, dtype=out.dtype, device=out.device)
+                self._a2a(back2, h.outg, h.counts, h.rcounts)
+                self.part.gather(back2, h.perm, out_get)
+                h.keep = h.keep + (back2,)
+            h.ev_done = comm.record_event() if comm is not None else None
         return h
 
     def wait(self, h):

@@ -132,6 +132,14 @@ def main():
         sm.apply_routed(h_i); sm.finish(h_i, out_i)
         sm.apply_routed(h_g); sm.finish(h_g, out_g)
         sm.wait(h_i); sm.wait(h_g)
+        # the fused form (one partition, one record exchange for write + get): decr what was added, read back
+        out_d = torch.empty(n, dtype=torch.int32); out_g2 = torch.empty(n, dtype=torch.int32)
+        h = sm.route(3, xt, yt, ones)
+        sm.apply_routed(h); sm.apply_routed_get(h); sm.finish(h, out_d, out_g2); sm.wait(h)
+        assert not out_g2.any(), "fused decr+get: every cell must be back at 0"
+        h = sm.route(2, xt, yt, ones)
+        sm.apply_routed(h); sm.apply_routed_get(h); sm.finish(h, out_d, out_g2); sm.wait(h)
+        assert (out_g2 == out_g).all(), "fused incr+get != separate incr, get"
     else:
         sm.apply_dev(2, xt, yt, ones, out_i)
         sm.apply_dev(0, xt, yt, None, out_g)
