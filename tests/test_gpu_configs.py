@@ -215,12 +215,17 @@ def test_scalar_abi_mirror_with_threads(G):
     m.close()
 
 
-def test_native_router_one_rank(G, oracle_mod, tmp_path):
+@pytest.mark.parametrize("over_rccl", [False, True])
+def test_native_router_one_rank(G, oracle_mod, tmp_path, monkeypatch, over_rccl):
     """include/smatrix_shard.h router section, the C library's own multi-GPU path, with all a 1-GPU box allows: one
     rank.  The batch still goes through the partition kernels, the (self-)exchange, the packed in-place apply and the
     result gather; answers and tables must be the oracle's, apply_then_get must equal apply + get, a planned placement
-    must not change anything, and the shard's file must be readable by the oracle."""
+    must not change anything, and the shard's file must be readable by the oracle.  over_rccl: the rank's own share
+    travels through RCCL as well (dlopen'ed library, ncclCommInitRank, grouped ncclSend/ncclRecv to itself) instead of
+    a device copy -- the call path N > 1 uses, as far as one GPU can take it."""
     import torch
+    if over_rccl:
+        monkeypatch.setenv("SMATRIX_SHARD_FORCE_RCCL", "1")
     from libsmatrix_amd.sharded import NativeShardedMatrix, Placement
     rng = np.random.default_rng(23)
     dev = torch.device("cuda", 0)
