@@ -64,6 +64,13 @@ for b in range(nb):
         if kind == 0:
             assert (a == bb).all(), "get batch %d" % b
     ops += n
+    if b % 7 == 3:
+        # scalar calls on cells just written (they enter the host-side mirror), left dirty across the next batch call
+        for k in range(min(n, 40)):
+            assert g.incr(int(x[k]), int(y[k]), 2) == o.incr(int(x[k]), int(y[k]), 2), "scalar incr"
+            assert g.get(int(x[k]), int(y[k])) == o.get(int(x[k]), int(y[k])), "scalar get"
+    if b % 11 == 5 and b < nb // 2:
+        g.flush()                                                # incremental write-out of the dirty rows (checked at the reopen)
     chk = g.get_batch(x, y)
     assert (chk == o.apply(0, x, y)).all(), "post-batch gets, batch %d kind %d n %d" % (b, kind, n)
     if b % 10 == 9:
@@ -79,5 +86,7 @@ for b in range(nb):
         g2.close()
 compare("end")
 st = g.stats()
-print("SOAK_OK batches=%d ops=%d rows=%d rounds=%d grown=%d rebalanced=%d" % (nb, ops, st["rows"], st["rounds"], st["rows_grown"], st["rows_rebalanced"]))
+print("SOAK_OK batches=%d ops=%d rows=%d rounds=%d grown=%d bulk_rounds=%d bulk_ops=%d long_probe_rounds=%d mirror_hits=%d flushes=%d" %
+      (nb, ops, st["rows"], st["rounds"], st["rows_grown"], st["bulk_rounds"], st["bulk_ops"], st["long_probe_rounds"],
+       st["scalar_cache_hits"], st["file_flushes"]))
 g.close(); o.close()
