@@ -657,7 +657,8 @@ def main():
         loads = [None] * world
         dist.all_gather_object(loads, int(m.exchanged_ops))
         mean = max(sum(loads) / world, 1)
-        shard_info = {"router": "C library (RCCL send/recv groups)", "ops_applied_over_mean": [round(v / mean, 3) for v in loads]} if args.c_router else {"rows_placed_by_load": len(m.placement.place),
+        shard_info = {"router": "C library (RCCL send/recv groups)", "rows_placed_by_load": len(m.placement.place),
+                      "ops_applied_over_mean": [round(v / mean, 3) for v in loads]} if args.c_router else {"rows_placed_by_load": len(m.placement.place),
                       "hash_range_widths": ([round((b - a) / 2.0 ** 32, 4) for a, b in
                                              zip([0] + m.placement.cuts, m.placement.cuts + [1 << 32])]
                                             if m.placement.cuts is not None else "equal"),

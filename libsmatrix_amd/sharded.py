@@ -601,13 +601,46 @@ class NativeShardedMatrix:
         if not self._h:
             raise ValueError("smatrix_shard_open() failed")
         self.local = _BorrowedMatrix(self._lib, self._lib.smatrix_shard_local(self._h))
+        self._placed = False
+        self.placement = Placement(world)
+
+    def _plan_from_first_batch(self, x, hot_rows=256):
+        """COLLECTIVE, once: with several ranks and an EMPTY matrix the first write batch doubles as a sample -- every rank's
+        most frequent row ids are gathered and plan_placement() (the same planner ShardedMatrix uses) gives the hot rows to
+        shards one by one and the tail hash ranges of unequal width; the tables go to the library
+        (smatrix_shard_set_placement).  Under Zipf(1.1) equal ranges leave the hottest row's owner with 1.9x the mean load."""
+        if self._placed or self.world == 1 or not dist.is_initialized():
+            self._placed = True
+            return
+        self._placed = True
+        rows = [None] * self.world
+        dist.all_gather_object(rows, int(self.local.stats()["rows"]))
+        if sum(rows) or os.environ.get("SMATRIX_SHARD_PLACE", "1") == "0":
+            return                                       # rows exist already: they stay where equal ranges put them
+        mine = {}
+        if x.numel():
+            ux, cnt = torch.unique(x, return_counts=True)
+            top = torch.topk(cnt, min(hot_rows, ux.numel())).indices
+            mine = {int(a) & 0xFFFFFFFF: int(c) for a, c in zip(ux[top].tolist(), cnt[top].tolist())}
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (mine, int(x.numel())))
+        counts, total = {}, 0
+        for part, n in parts:
+            total += n
+            for a, c in part.items():
+                counts[a] = counts.get(a, 0) + c
+        self.placement = plan_placement(counts, total, self.world, hot_rows)
+        self.set_placement(self.placement)
 
     def apply_dev(self, op, x, y, v, out, stream=None):
+        if op != OP_GET:
+            self._plan_from_first_batch(x)
         n = x.numel()
         self._lib.smatrix_shard_apply_dev(self._h, op, n, x.data_ptr(), y.data_ptr(),
                                           v.data_ptr() if v is not None else None, out.data_ptr(), stream)
 
     def apply_then_get_dev(self, op, x, y, v, out, out_get, stream=None):
+        self._plan_from_first_batch(x)
         self._lib.smatrix_shard_apply_then_get_dev(self._h, op, x.numel(), x.data_ptr(), y.data_ptr(), v.data_ptr(),
                                                    out.data_ptr(), out_get.data_ptr(), stream)
 

@@ -77,6 +77,21 @@ def test_config2_reference_checksums_1e7(G):
     gen.close()
 
 
+def test_config2_reference_checksums_4e8():
+    """BASELINE config 2 at FULL size: exactly 4e8 ops of the Zipf(1.1)^2 stream (generated on the device, 24 batches of
+    2^24) on a fresh matrix must leave 1 000 000 rows, 100 401 767 nnz and a hottest row of 935 410 columns -- the figures
+    the unmodified reference produced in 263 s on one CPU thread -- plus the 10^7-op figures on the way.
+    (bench.py runs the same replay after its timed region.)"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    res = bench.verify_config2(torch, dev, None, None, 1 << 24, 0)
+    assert res["matches_reference"]
+    assert res["at_4e8_ops"] == {"rows": 1000000, "nnz": 100401767, "max_rowlen": 935410}
+    assert res["at_1e7_ops"]["sum_get"] == 52480898544
+
+
 def test_batched_returns_under_duplication(G, oracle_mod):
     """k_apply_agg<INCR/DECR> (batches >= 1024 ops fold duplicate keys in LDS): the per-op RETURN values.
     With one increment value per key the multiset of a key's returns is the same in every serialisation
