@@ -356,7 +356,8 @@ struct Matrix {
   // the bulk path (k_fix_*): taken in round 0 when the previous write batch deferred a large share of its ops
   bool bulk_enabled = true;             // SMATRIX_BULK=0 switches it off
   bool expect_bulk = true;              // an empty matrix creates its rows: expect it
-  uint32_t fix_min = 1u << 18;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN)
+  uint32_t fix_min = 1u << 14;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN): its fixed cost is ~6 small
+                                        // launches and 3 read-backs, about two rounds of the loop it replaces
   DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped;
   uint32_t fx_dir_size = 0;             // directory size fx_cnt / fx_cur / fx_pos were laid out (and zeroed) for
   DevBuf<uint64_t> fx_excl, fx_tiles;
@@ -613,7 +614,7 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   const uint64_t new_base0 = m->arena_next;
   const uint64_t rows_bound = std::min<uint64_t>(nd, m->dir_used);
   for (uint32_t c = 0; c <= FIX_MAX_LG - ROW_FIRST_LG; c++) ensure_free_cap(m, c, rows_bound, s);
-  const dim3 fgrid(std::min<uint32_t>((rows_max + FIX_WAVES - 1) / FIX_WAVES, 8192));
+  const dim3 fgrid(std::max<uint32_t>(1, std::min<uint32_t>((rows_max + FIX_WAVES - 1) / FIX_WAVES, 8192)));   // (no row at all: the one id this path leaves to prep)
   hipLaunchKernelGGL((k_fix_rows<OP, FIX_MAX_LG - 1>), fgrid, dim3(64 * FIX_WAVES), 0, s,
                      m->d_ctl, m->d_dir, m->fx_touched.p, m->arena.base, m->fx_cnt.p, m->fx_cur.p, m->fx_excl.p, m->fx_grouped.p, y, v,
                      m->in_stride, out, dl_out, new_base0, m->fl);

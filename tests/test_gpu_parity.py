@@ -767,7 +767,8 @@ def test_hypothesis_small_sequences_vs_oracle(G, oracle_mod, monkeypatch, bulk_m
     batch = st.tuples(st.sampled_from([1, 2, 3]), st.lists(op, min_size=1, max_size=40))
     program = st.lists(batch, min_size=1, max_size=8)
 
-    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=int(__import__("os").environ.get("SMX_HYP_EXAMPLES", "60")), deadline=None,
+              suppress_health_check=list(HealthCheck))
     @given(program)
     def run(prog):
         g, o = G(), oracle_mod.Oracle()
