@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
     Ctl* ctl, DirSlot* dir, const uint32_t* touched, uint8_t* arena, uint32_t* cnt, uint32_t* cursor, const uint64_t* excl,
     const uint32_t* grouped, const uint32_t* __restrict__ ys, const uint32_t* __restrict__ vs, uint32_t st,
     uint32_t* __restrict__ out, uint32_t* defer_out, uint64_t new_base0, FreeLists fl) {
-  static_assert(OP == OP_INCR || OP == OP_DECR, "the bulk path takes the commutative writers");
+  static_assert(OP != OP_GET, "the bulk path takes writers (set: any value lands here, duplicates are resolved after the rounds, k_set_*)");
   static_assert(MAXLG == FIX_MAX_LG || MAXLG + 1 == FIX_MAX_LG, "two passes");
   constexpr uint32_t SMAX = 1u << MAXLG;
   __shared__ uint64_t l_tab[FIX_WAVES][2][SMAX];
@@ -1352,7 +1352,8 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
               }
             }
             uint32_t* vp = reinterpret_cast<uint32_t*>(&T[slot]) + 1;
-            res = OP == OP_INCR ? atomicAdd(vp, Vl) + Vl : atomicSub(vp, Vl) - Vl;        // :241 / :252
+            if (OP == OP_SET) { atomicExch(vp, Vl); res = Vl; }                           // :230
+            else res = OP == OP_INCR ? atomicAdd(vp, Vl) + Vl : atomicSub(vp, Vl) - Vl;   // :241 / :252
             pending = false;
           }
           used += (uint32_t)__popcll(__ballot(inserted));

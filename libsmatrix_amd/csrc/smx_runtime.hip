@@ -665,7 +665,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
-    if (round == 0 && m->bulk_enabled && m->expect_bulk && (op == OP_INCR || op == OP_DECR) && n >= m->fix_min) {
+    if (round == 0 && m->bulk_enabled && m->expect_bulk && op != OP_GET && n >= m->fix_min) {
       // the previous batch deferred a large share of its ops (bulk load, young matrix): look at this one's count
       // before prep -- one extra read-back, only in this regime -- and group a large remainder by row instead of
       // walking it through a round per doubling
@@ -678,8 +678,9 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         m->st.deferred_ops += nd0;
         m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
         uint32_t* dl2 = m->defer[1].p;
-        const uint32_t nd2 = op == OP_INCR ? run_bulk_t<OP_INCR>(m, nd0, dl, dl2, x, y, v, out, s)
-                                           : run_bulk_t<OP_DECR>(m, nd0, dl, dl2, x, y, v, out, s);
+        const uint32_t nd2 = op == OP_INCR   ? run_bulk_t<OP_INCR>(m, nd0, dl, dl2, x, y, v, out, s)
+                             : op == OP_DECR ? run_bulk_t<OP_DECR>(m, nd0, dl, dl2, x, y, v, out, s)
+                                             : run_bulk_t<OP_SET>(m, nd0, dl, dl2, x, y, v, out, s);
         if (m->trace_rounds)
           fprintf(stderr, "[smatrix] batch %llu bulk path: %u deferred ops grouped by row, %u handed back, rows=%u\n",
                   (unsigned long long)m->st.batches, nd0, nd2, m->dir_used);

@@ -366,8 +366,13 @@ def test_bulk_path_groups_deferred_ops_by_row(G, oracle_mod, monkeypatch):
         ka, kb = per_key_sorted(x, y, a), per_key_sorted(x, y, b)
         assert (ka[1] == kb[1]).all(), rnd
         assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rnd
+    # set through the same path: new rows, duplicates inside the batch resolve highest-index-wins afterwards
+    x = rng.integers(200000, 203000, 50000, dtype=np.uint32); y = rng.integers(1, 400, 50000, dtype=np.uint32)
+    v = rng.integers(0, 1 << 32, 50000, dtype=np.uint64).astype(np.uint32)
+    assert (g.apply(1, x, y, v) == v).all() and (o.apply(1, x, y, v) == v).all()
+    assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
     st = g.stats()
-    assert st["bulk_rounds"] >= 4 and st["bulk_ops"] > 100000, st
+    assert st["bulk_rounds"] >= 5 and st["bulk_ops"] > 150000, st
     rows = o.list_rows()
     assert st["rows"] == rows.size
     assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
