@@ -104,6 +104,8 @@ typedef struct {
   uint64_t bulk_ops;             /* ops finished on that path */
   uint64_t file_flushes;         /* file mode: write-outs of dirty rows (smatrix_flush, SMATRIX_FLUSH_EVERY, close) */
   uint64_t file_rows_written;    /* rows those write-outs wrote (a clean row is never rewritten) */
+  uint64_t file_leaked_bytes;    /* row blocks that grown rows left behind in the file since it was opened */
+  uint64_t file_compactions;     /* smatrix_compact runs */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];
@@ -119,6 +121,10 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
  * close is its only barrier (:113-133).  SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch, SMATRIX_FSYNC=1
  * adds fsync() after the row blocks and after the entries.  Memory mode: no-op.  Returns 0. */
 int smatrix_flush(smatrix_t* self);
+/* File mode: rewrites the backing file without the blocks that grown rows have left behind (like the reference's, the
+ * file otherwise only grows, src/smatrix.c:430-436): all rows into a new file next to it, fsync, rename over the old
+ * one.  Needs room for a second copy while it runs.  SMATRIX_COMPACT_AT_CLOSE=1 does it at close.  Returns 0. */
+int smatrix_compact(smatrix_t* self);
 /* on: time every round-0 op kernel with HIP events on its stream (adds one sync per
  * batch); resets the kernel_* accumulators.  Also enabled by SMATRIX_PROFILE=1. */
 void smatrix_profile(smatrix_t* self, int on);

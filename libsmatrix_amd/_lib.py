@@ -16,7 +16,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rows", "dir_slots", "arena_units", "arena_mapped", "arena_free_units", "batches", "rounds",
         "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced", "long_probe_rounds", "scalar_cache_hits", "scalar_cache_flushes",
-        "scalar_cache_flushed_cells", "bulk_rounds", "bulk_ops", "file_flushes", "file_rows_written")] + [
+        "scalar_cache_flushed_cells", "bulk_rounds", "bulk_ops", "file_flushes", "file_rows_written", "file_leaked_bytes",
+        "file_compactions")] + [
         ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
 
 
@@ -68,6 +69,7 @@ def load():
         "smatrix_stats": (None, [H, C.POINTER(Stats)]),
         "smatrix_profile": (None, [H, C.c_int]),
         "smatrix_flush": (C.c_int, [H]),
+        "smatrix_compact": (C.c_int, [H]),
         "smatrix_row_info": (C.c_int, [H, C.c_uint32, u32p, u32p]),
         "smatrix_row_slots": (C.c_uint32, [H, C.c_uint32, u32p, C.c_uint32]),
         "smatrix_device_available": (C.c_int, []),

@@ -350,6 +350,7 @@ struct Matrix {
   DevBuf<uint64_t> row_ret;             // scalar getrow: pooled device buffer for rows that outgrow the pinned one
   uint32_t* h_row = nullptr;            // pinned: {count, spare, big[2], offsets[2] (u64)} + pairs written by the kernel itself
   void* file_index = nullptr;           // FileIndex (smx_file.inc): where every row lives in the backing file
+  bool compact_at_close = false;        // SMATRIX_COMPACT_AT_CLOSE=1: close rewrites the file without leaked blocks
   bool file_fsync = false;              // SMATRIX_FSYNC=1: fsync between the row blocks and the CMAP entries, and after
   uint64_t flush_every = 0;             // SMATRIX_FLUSH_EVERY=N: checkpoint the file after every N write batches
   uint64_t dbg_after = 0;               // SMATRIX_DBG_AFTER: batch number from which a measurement build's debug mode applies
@@ -824,6 +825,17 @@ int smatrix_flush(smatrix_t* self) {
   return 0;
 }
 
+// include/smatrix_batch.h: the backing file rewritten without leaked blocks (no-op in memory mode)
+int smatrix_compact(smatrix_t* self) {
+  Matrix* m = M(self);
+  if (m->fname.empty() || !self->fd) return 0;
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
+  file_compact(self, m);
+  return 0;
+}
+
 int smatrix_device_available(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -879,6 +891,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_FSYNC")) m->file_fsync = *a == '1';
+  if (const char* a = getenv("SMATRIX_COMPACT_AT_CLOSE")) m->compact_at_close = *a == '1';
   if (const char* a = getenv("SMATRIX_FLUSH_EVERY")) m->flush_every = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
@@ -907,7 +920,8 @@ void smatrix_close(smatrix_t* self) {
     {
       std::lock_guard<std::mutex> g(m->mu);
       cache_sync(m, true);
-      if (!m->fname.empty() && self->fd && m->dirty) file_flush(self, m);   // a matrix that was only read has nothing to persist
+      if (!m->fname.empty() && self->fd && m->compact_at_close) file_compact(self, m);
+      else if (!m->fname.empty() && self->fd && m->dirty) file_flush(self, m);   // a matrix that was only read has nothing to persist
       (void)hipStreamSynchronize(m->stream);
       PhaseClock clk(m->trace_rounds, "close");
       m->arena.destroy();
@@ -1339,6 +1353,7 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   m->st.scalar_cache_hits = m->cache.hits.load();
   m->st.scalar_cache_flushes = m->cache.flushes.load();
   m->st.scalar_cache_flushed_cells = m->cache.flushed_cells.load();
+  m->st.file_leaked_bytes = m->file_index ? file_leaked(m) : 0;
   *out = m->st;
 }
 

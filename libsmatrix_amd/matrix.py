@@ -169,6 +169,10 @@ class SparseMatrix:
         """file mode: dirty rows reach the backing file now (include/smatrix_batch.h smatrix_flush)"""
         self._lib.smatrix_flush(self._h)
 
+    def compact(self):
+        """file mode: rewrite the backing file without leaked blocks (include/smatrix_batch.h smatrix_compact)"""
+        self._lib.smatrix_compact(self._h)
+
     def profile(self, on=True):
         self._lib.smatrix_profile(self._h, int(on))
 
