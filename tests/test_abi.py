@@ -59,3 +59,16 @@ def test_open_without_gpu_fails_loudly(built):
         pytest.skip("a GPU is present")
     with pytest.raises(ValueError):
         libsmatrix_amd.SparseMatrix()
+
+
+def test_headers_and_c_caller_compile_as_c99(built, tmp_path):
+    """include/*.h are C headers for C callers (JNI, Ruby, plain C): every one of them, and the C test program that uses
+    the drop-in calls, the batch API, flush and the shard helpers, compiles as strict C99 and links against smatrix.so"""
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(os.listdir(inc)):
+        src = tmp_path / ("inc_" + h + ".c")
+        src.write_text('#include "%s"\nint main(void) { return 0; }\n' % h)
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + inc, "-c", str(src), "-o", str(tmp_path / "o.o")], check=True)
+    exe = str(tmp_path / "abi_known_answers")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + inc, os.path.join(ROOT, "tests", "c", "abi_known_answers.c"),
+                    os.path.join(built, "smatrix.so"), "-Wl,-rpath," + built, "-o", exe], check=True)

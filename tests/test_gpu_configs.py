@@ -153,6 +153,23 @@ def test_mem_field_tracks_the_tables(G):
     m.close()
 
 
+def test_c_program_known_answers(tmp_path, oracle_mod):
+    """a plain C caller (tests/c/abi_known_answers.c) compiled against include/*.h and linked with lib/smatrix.so: the
+    known answers of SURVEY.md A.1 through the eight drop-in calls, the batch API interleaved with scalar calls, flush;
+    in file mode the oracle then reads what the C program left"""
+    inc, lib = os.path.join(ROOT, "include"), os.path.join(ROOT, "libsmatrix_amd", "lib")
+    exe = str(tmp_path / "abi_known_answers")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I" + inc, os.path.join(ROOT, "tests", "c", "abi_known_answers.c"),
+                    os.path.join(lib, "smatrix.so"), "-Wl,-rpath," + lib, "-o", exe], check=True)
+    for args in ([], [str(tmp_path / "c_caller.smx")]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "C_ABI_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    r = oracle_mod.Oracle(str(tmp_path / "c_caller.smx"))
+    assert r.get(1, 2) == 17 and r.rowlen(3) == 12 and r.get(77, 1000) == 11 and r.rowlen(77) == 1000
+    assert r.get(2, 0) == 1 and r.rowlen(2) == 3          # the (0,v) cell is counted after a reload (quirk Q2)
+    r.close()
+
+
 def test_scalar_abi_cell_mirror(G, oracle_mod, tmp_path):
     """The scalar ABI answers calls on cells it has already seen from a host-side mirror and writes the values back
     in one batched set before anything else can look (DESIGN.md "scalar ABI"): every return value, every batch read
