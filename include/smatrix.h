@@ -28,8 +28,10 @@
  * The handle's leading fields mirror the reference's smatrix_t
  * (src/smatrix.h:76-85) far enough for code that peeks at `mem`
  * (examples/smatrix_example.c:72); everything else lives behind `impl`.
- * Scalar calls cost one device round trip each: throughput comes from the
- * additive batched API in smatrix_batch.h.
+ * A scalar call on a cell the library has not seen yet costs one device round
+ * trip; calls on cells it has seen are answered from a host-side mirror and
+ * written back before anything else looks at the tables (DESIGN.md "scalar ABI").
+ * Bulk throughput comes from the additive batched API in smatrix_batch.h.
  */
 #ifndef SMATRIX_H
 #define SMATRIX_H
