@@ -56,7 +56,7 @@ int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t*
 int smatrix_getrow_batch(smatrix_t* self, size_t n, const uint32_t* x, const uint64_t* offsets,
                          uint32_t* ret, uint32_t* counts);
 
-/* device-pointer flavours */
+/* device-pointer flavours (d_out may be NULL when the results are not wanted; d_v is not read by get) */
 int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d_x,
                             const uint32_t* d_y, const uint32_t* d_v, uint32_t* d_out,
                             void* hip_stream);

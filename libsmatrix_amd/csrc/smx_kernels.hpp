@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(256) void k_rowlen(DirSlot* dir, uint32_t dmask, ui
 // offsets[r+1]-offsets[r] pairs; counts[r] = pairs written.
 //   k_getrow      one wave per row, 128 cells (1 KiB) per step with 16-byte loads; rows of more
 //                 than GETROW_WAVE_MAX cells are only noted down in `big`
-//   k_getrow_big  one 1024-lane workgroup per noted row, 2048 cells per step
+//   k_getrow_big  one 1024-lane workgroup per noted row -- per 32768-cell SEGMENT of a giant one --, 2048 cells per step
 constexpr uint32_t GETROW_WAVE_MAX = 8192;
 
 __device__ inline uint32_t getrow_cap(const uint64_t* offsets, uint32_t r) {
@@ -2012,27 +2012,108 @@ __global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, ui
   }
 }
 
+// Rows noted down by k_getrow are cut into SEGMENTS of GETROW_SEG cells, one workgroup each, so that one giant row
+// (config 2: 2 M slots, 16 MB) is read by as many workgroups as it has segments instead of by one:
+//   k_getrow_plan       seg_start[b] = first segment id of noted row b (rows of up to 2 segments' worth stay whole)
+//   k_getrow_big<true>  per segment of a CUT row: the number of non-empty cells -> seg_cnt[]
+//   k_getrow_big<false> per segment: the pairs, in slot order, at  offset + (pairs in the segments before it)
+// A row that stays whole needs no count pass: its single workgroup compacts from rank 0 as before.
+constexpr uint32_t GETROW_SEG = 32768;
+
+__device__ inline uint32_t getrow_nseg(uint32_t size) { return size >= 2 * GETROW_SEG ? size / GETROW_SEG : 1u; }
+
+__global__ __launch_bounds__(1024) void k_getrow_plan(DirSlot* dir, uint32_t dmask, const uint32_t* __restrict__ xs,
+                                                      const uint32_t* big, uint32_t* seg_start) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t s_base;
+  const uint32_t nbig = big[0];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nbig; b0 += 1024) {
+    const uint32_t b = b0 + threadIdx.x;
+    uint32_t v = 0;
+    if (b < nbig) {
+      uint4 s;
+      dir_find(dir, dmask, xs[big[1 + b]], &s);
+      v = getrow_nseg(1u << meta_lg(s.x));
+    }
+    uint32_t incl = v;                                    // inclusive scan inside the wave
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = s_base, total = 0;
+    for (uint32_t i = 0; i < 16; i++) { const uint32_t t = wsum[i]; if (i < w) before += t; total += t; }
+    if (b < nbig) seg_start[b] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) seg_start[nbig] = s_base;
+}
+
+template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_getrow_big(DirSlot* dir, uint32_t dmask, uint8_t* arena,
                                                      const uint32_t* __restrict__ xs,
                                                      const uint64_t* __restrict__ offsets,
                                                      uint64_t* __restrict__ ret,
-                                                     uint32_t* __restrict__ counts, const uint32_t* big) {
+                                                     uint32_t* __restrict__ counts, const uint32_t* big,
+                                                     const uint32_t* __restrict__ seg_start, uint32_t* seg_cnt) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t s_written;
   const uint32_t nbig = big[0];
+  const uint32_t nseg_all = nbig ? seg_start[nbig] : 0;
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint64_t lt = (1ull << lane) - 1;
-  for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+  auto block_sum = [&](uint32_t v) -> uint32_t {          // sum over the workgroup, to every lane
+    for (uint32_t d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    __syncthreads();
+    if (lane == 0) wsum[w] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < 16; i++) t += wsum[i];
+    __syncthreads();
+    return t;
+  };
+  for (uint32_t t = blockIdx.x; t < nseg_all; t += gridDim.x) {
+    uint32_t lo = 0, hi = nbig;                           // the noted row whose segments include t
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t b = lo, first = seg_start[b], nseg = seg_start[b + 1] - first, g = t - first;
+    if (COUNT && nseg == 1) continue;
     const uint32_t r = big[1 + b];
     uint4 s;
     dir_find(dir, dmask, xs[r], &s);
     const uint32_t size = 1u << meta_lg(s.x);
+    const uint4* cells = reinterpret_cast<const uint4*>(row_cells(arena, s.z));
+    const uint32_t p_begin = nseg == 1 ? 0u : g * GETROW_SEG, p_end = nseg == 1 ? size : p_begin + GETROW_SEG;
+    if (COUNT) {
+      uint32_t c = 0;
+      for (uint32_t p0 = p_begin; p0 < p_end; p0 += 2048) {
+        const uint4 q = cells[(p0 >> 1) + threadIdx.x];
+        c += ((q.x | q.y) != 0) + ((q.z | q.w) != 0);
+      }
+      c = block_sum(c);
+      if (threadIdx.x == 0) seg_cnt[t] = c;
+      continue;
+    }
     const uint64_t off = offsets[r];
     const uint32_t cap = getrow_cap(offsets, r);
-    const uint4* cells = reinterpret_cast<const uint4*>(row_cells(arena, s.z));
-    if (threadIdx.x == 0) s_written = 0;
+    uint32_t before_me = 0;
+    if (nseg > 1) {
+      uint32_t mine = 0, all = 0;
+      for (uint32_t i = threadIdx.x; i < nseg; i += 1024) { const uint32_t c = seg_cnt[first + i]; all += c; if (i < g) mine += c; }
+      before_me = block_sum(mine);
+      if (g == 0) {                                         // the row's first segment also reports the row's count
+        all = block_sum(all);
+        if (threadIdx.x == 0) counts[r] = all > cap ? cap : all;
+      }
+    }
+    if (threadIdx.x == 0) s_written = before_me;
     __syncthreads();
-    for (uint32_t p0 = 0; p0 < size; p0 += 2048) {
+    for (uint32_t p0 = p_begin; p0 < p_end; p0 += 2048) {
       const uint32_t written = s_written;
       if (written >= cap) break;
       const uint4 c = cells[(p0 >> 1) + threadIdx.x];            // size is a multiple of 2048 here
@@ -2050,7 +2131,7 @@ __global__ __launch_bounds__(1024) void k_getrow_big(DirSlot* dir, uint32_t dmas
       if (threadIdx.x == 0) s_written = written + total;
       __syncthreads();
     }
-    if (threadIdx.x == 0) counts[r] = s_written > cap ? cap : s_written;
+    if (nseg == 1 && threadIdx.x == 0) counts[r] = s_written > cap ? cap : s_written;
     __syncthreads();
   }
 }

@@ -329,6 +329,7 @@ struct Matrix {
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
   DevBuf<uint64_t> soff;
   DevBuf<uint32_t> big;                 // getrow: rows too large for one wave
+  DevBuf<uint32_t> seg;                 // getrow: their segments (first segment per row, then a count per segment)
   uint32_t* d_small = nullptr;          // 16 words of scratch
   uint32_t* h_small = nullptr;          // pinned
 
@@ -938,7 +939,7 @@ void smatrix_close(smatrix_t* self) {
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
-      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release();
+      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
       if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
@@ -966,6 +967,7 @@ int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
+  if (!d_out && n) { m->so.need(n); d_out = m->so.p; }    // results not wanted: they land in the library's own staging buffer
   apply_dev_locked(self, op, n, d_x, d_y, d_v, d_out, s);
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -981,6 +983,7 @@ int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* 
   cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   m->in_stride = width;
+  if (!d_out && n) { m->so.need(n); d_out = m->so.p; }
   apply_dev_locked(self, op, n, d_records, d_records + 1, d_records + 2, d_out, s);
   m->in_stride = 1;
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
@@ -1055,6 +1058,23 @@ int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t*
 }
 
 namespace {
+// the noted (large) rows of a getrow launch: plan their segments, count the cut rows' segments, write
+void launch_getrow_big(Matrix* m, hipStream_t s, uint32_t n, uint32_t grid, const uint32_t* x, const uint64_t* off,
+                       uint64_t* ret, uint32_t* counts, const uint32_t* big) {
+  // seg: [0 .. n] first segment of each noted row, then one count per segment (a row table of c cells has at most
+  // c / GETROW_SEG segments, the arena holds mapped / 8 cells)
+  const size_t segs = (size_t)n + m->arena.mapped / 8 / GETROW_SEG + 2;
+  m->seg.need((size_t)n + 1 + segs);
+  uint32_t* seg_start = m->seg.p;
+  uint32_t* seg_cnt = m->seg.p + n + 1;
+  hipLaunchKernelGGL(k_getrow_plan, dim3(1), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, x, big, seg_start);
+  hipLaunchKernelGGL(k_getrow_big<true>, dim3(grid), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
+                     x, off, ret, counts, big, seg_start, seg_cnt);
+  hipLaunchKernelGGL(k_getrow_big<false>, dim3(grid), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
+                     x, off, ret, counts, big, seg_start, seg_cnt);
+  HIP_OK(hipGetLastError());
+}
+
 void launch_getrow(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* x, const uint64_t* off,
                    uint64_t* ret, uint32_t* counts) {
   m->big.need((size_t)n + 1);
@@ -1062,11 +1082,10 @@ void launch_getrow(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* x, cons
   uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
   hipLaunchKernelGGL(k_getrow, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x,
                      off, ret, counts, m->big.p);
-  // rows of more than 8192 cells were only noted down: a workgroup per row, at most the rows asked for (with none
-  // noted the launch is a few idle workgroups)
-  hipLaunchKernelGGL(k_getrow_big, dim3(std::min<uint32_t>(n, 512)), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
-                     x, off, ret, counts, m->big.p);
-  HIP_OK(hipGetLastError());
+  // rows of more than 8192 cells were only noted down: a workgroup per row -- per segment of a giant row -- (with
+  // none noted the three launches are a few idle workgroups)
+  const uint64_t most = (uint64_t)n + m->arena.mapped / 8 / GETROW_SEG;
+  launch_getrow_big(m, s, n, (uint32_t)std::min<uint64_t>(most, 2048), x, off, ret, counts, m->big.p);
 }
 }  // namespace
 
@@ -1313,9 +1332,7 @@ uint32_t smatrix_getrow(smatrix_t* self, uint32_t x, uint32_t* ret, size_t ret_l
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(s));
     if (h[2]) {                                           // a row of more than 8192 cells: the workgroup-per-row kernel
-      hipLaunchKernelGGL(k_getrow_big, dim3(1), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, h + 1, offs,
-                         pairs, h, h + 2);
-      HIP_OK(hipGetLastError());
+      launch_getrow_big(m, s, 1, 256, h + 1, offs, pairs, h, h + 2);
       HIP_OK(hipStreamSynchronize(s));
     }
     const uint32_t count = h[0];

@@ -419,7 +419,8 @@ def _cf_build_device(m, rows, torch, chunk_rows=1 << 17):
     for r0 in range(0, rows, chunk_rows):
         n = (min(rows, r0 + chunk_rows) - r0) * CF_PER_ROW
         gen.fill_device(r0 * CF_PER_ROW, n, x.data_ptr(), y.data_ptr(), st)
-        m.apply_batch_dev(2, n, x.data_ptr(), y.data_ptr(), ones.data_ptr(), out.data_ptr(), st)
+        # (every other chunk without a result array: d_out may be NULL, include/smatrix_batch.h)
+        m.apply_batch_dev(2, n, x.data_ptr(), y.data_ptr(), ones.data_ptr(), out.data_ptr() if (r0 // chunk_rows) % 2 == 0 else None, st)
     torch.cuda.synchronize()
     return gen
 

@@ -601,8 +601,18 @@ def test_big_rows_subcounters(G, oracle_mod, tmp_path):
         full = g.getrow(r)
         assert full.shape[0] == ne.shape[0] == o.getrow(r).shape[0] and (full == ne).all()
         assert (g.getrow(r, 8 * 5000) == ne[:5000]).all() and g.getrow(r, 20).shape[0] == 3
+        # these rows are cut into 32768-cell segments, one workgroup each: a buffer that ends inside the 4th segment
+        assert slots.shape[0] >= 4 * 32768
+        head = slots[:3 * 32768]
+        cut = int(((head[:, 0] != 0) | (head[:, 1] != 0)).sum()) + 17
+        assert (g.getrow(r, 8 * cut) == ne[:cut]).all()
     off, pairs, cnt = g.m.getrow_batch(np.array([0, 1, 2, 77], dtype=np.uint32))
     assert cnt.tolist() == [o.rowlen(0), o.rowlen(1), o.rowlen(2), 0]
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    for i in range(3):
+        slots = np.asarray(g.row_slots(i))
+        ne = slots[(slots[:, 0] != 0) | (slots[:, 1] != 0)]
+        assert (pairs[int(off[i]):int(off[i]) + int(cnt[i])] == ne).all()
     # land exactly on thresholds: one op at a time around the 2^15 -> 2^16 doubling of a fresh row
     keys = np.arange(1, (1 << 15) + 40, dtype=np.uint32) * 7
     g.apply(2, np.full(keys.size - 80, 9, np.uint32), keys[:-80], np.ones(keys.size - 80, np.uint32))
