@@ -298,7 +298,7 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
 //           at the slot it found)
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
-                                     bool* deferred, LongProbe* lp) {
+                                     bool* deferred, LongProbe* lp, bool dbg_noticket = false) {
   uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
@@ -324,8 +324,10 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         // while used <= size/2 (src/smatrix.c:346), otherwise it grows first
         // (the snapshot taken with the directory slot spares a row that already stands at the
         // threshold two contended atomics per op; a stale/low snapshot only costs the atomics)
-        uint32_t* ticket;
-        if (lg >= BIG_LG) {
+        uint32_t* ticket = nullptr;
+        if (dbg_noticket) {
+          // measurement builds only (SMX_AGG_DBG 5): inserts without their `used` ticket
+        } else if (lg >= BIG_LG) {
           // big row: take the ticket from one of the sub-counters (its quota is a share of the room)
           // (spread by lane as well: a handful of retried ops all sit in one wave and must not
           //  queue on the single share of one sub-counter)
@@ -349,7 +351,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull,
                                   (unsigned long long)pack_cell(Y, first));
         if (prev == 0) return first;
-        atomicSub(ticket, 1u);                           // lost the slot: give the ticket back
+        if (!dbg_noticket) atomicSub(ticket, 1u);        // lost the slot: give the ticket back
         c = prev;
         continue;                                        // re-examine what is there now
       }
@@ -387,14 +389,14 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
 // directory lookup + the per-op body (MODE as in apply_row)
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
-                                     uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr) {
+                                     uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false) {
   uint4 s;
   DirSlot* d = dir_find(dir, dmask, X, &s);
   if (!d || s.z == 0) {
     *deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
     return 0;
   }
-  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp);
+  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket);
 }
 
 #ifndef SMX_APPLY_SGPRS
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
         LongProbe lp{false, nullptr, 0, 0};
-        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp);
+        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5);
         if (lp.need) { deferred = true; ctl->n_long = 1; }
         old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
       }

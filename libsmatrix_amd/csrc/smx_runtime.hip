@@ -667,6 +667,15 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
+#if defined(SMX_AGG_DBG) && SMX_AGG_DBG == 5
+    // measurement build "inserts without tickets": rows overfill and their deferred ops never converge -- only the
+    // round-0 launch is of interest, what it deferred is dropped
+    if (m->dbg_after && m->st.batches >= m->dbg_after) {
+      ctl_read(m, s);
+      if (timed0) { account_kernel_time(m, op, n); timed0 = false; }
+      break;
+    }
+#endif
     if (round == 0 && m->bulk_enabled && m->expect_bulk && op != OP_GET && n >= m->fix_min) {
       // the previous batch deferred a large share of its ops (bulk load, young matrix): look at this one's count
       // before prep -- one extra read-back, only in this regime -- and group a large remainder by row instead of
