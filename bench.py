@@ -347,10 +347,17 @@ def touch_hbm(torch, dev, nbytes):
 def run_config3(torch, dev, rows=13000000, reps=5):
     from libsmatrix_amd import SparseMatrix
     touch_hbm(torch, dev, rows * 256 * 8 * 1.6)
+    # built twice: the first 27 GB build of the first process on a freshly leased box has been seen at 1.2-1.6 s against
+    # 0.24 s for every later one, same kernels and round counts (driver-side first use of that much HBM, which the
+    # touch above does not always absorb) -- both are reported, `build_s` is the second
+    m = SparseMatrix()
+    build_first_s = build_cf(torch, dev, m, rows)
+    m.close()
     m = SparseMatrix()
     build_s = build_cf(torch, dev, m, rows)
     res = scan_cf(torch, dev, m, rows, reps)
     res["build_s"] = build_s
+    res["build_first_s"] = build_first_s
     res["build_Gops_per_s"] = rows * CF_PER_ROW / build_s / 1e9
     res["workload"] = "config-3: smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz (CF shape), table built on the device" % (rows, res["nnz"])
     m.close()

@@ -78,6 +78,9 @@ open(os.path.join(P, RND + "_rocprof_kernel_stats.txt"), "w").write(
 # the bench line must carry the traffic of THIS refresh: bench.py reads profiles/pmc.json, which was just rewritten
 b["roofline"]["traffic"] = int(bytes_agg); b["roofline_get"]["traffic"] = int(bytes_get)
 b["roofline"]["memory_side_atomics"] = agg["atom"]
+for r in ("roofline", "roofline_get"):
+    b[r].pop("traffic_note", None)      # that note was about the pmc.json this refresh has just replaced
+    b[r]["traffic_source"] = "profiles/%s_pmc_summary.txt (PMC passes of this same refresh)" % RND
 json.dump(b, open(os.path.join(P, RND + "_bench.json"), "w"))
 print(hdr)
 # config 3: the getrow scan
