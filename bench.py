@@ -242,13 +242,49 @@ def verify_config2(torch, dev, xs_ring, ys_ring, B, n_ring):
                 sum_get = int(out[:P1].sum(dtype=torch.int64).item())
                 res["at_1e7_ops"] = dict(zip(("rows", "nnz", "max_rowlen"), census()), sum_get=sum_get)
     res["at_4e8_ops"] = dict(zip(("rows", "nnz", "max_rowlen"), census()))
+    res["getrow_all_rows_at_4e8"] = scan_config2(torch, dev, m, stream)
     m.close(); gen.close()
     want = {"at_1e7_ops": {"rows": 561596, "nnz": 4463637, "max_rowlen": 159472, "sum_get": 52480898544},
             "at_4e8_ops": {"rows": 1000000, "nnz": 100401767, "max_rowlen": 935410}}
     res["matches_reference"] = res["at_1e7_ops"] == want["at_1e7_ops"] and res["at_4e8_ops"] == want["at_4e8_ops"]
+    g = res["getrow_all_rows_at_4e8"]
+    # getrow over every row: as many pairs as nnz, the values sum to the number of incr ops (every op added 1, y >= 1),
+    # and the hottest row -- 2 M slots, read by one workgroup per 32768-cell segment -- returns all its 935 410 pairs
+    res["matches_reference"] = res["matches_reference"] and g["pairs"] == want["at_4e8_ops"]["nnz"] and g["sum_of_values"] == P2 \
+        and g["max_row_pairs"] == want["at_4e8_ops"]["max_rowlen"]
     res["reference_figures"] = "SURVEY.md A.4 (compiled reference, this stream)"
     assert res["matches_reference"], (res, want)
     return res
+
+
+def scan_config2(torch, dev, m, stream, reps=3):
+    """smatrix_rowlen + smatrix_getrow over all 1 M rows of the config-2 table in one device call each (HIP events)"""
+    ids = torch.arange(1, N_IDS + 1, dtype=torch.int64, device=dev)
+    h = ids ^ (ids >> 16); h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h = h ^ (h >> 13); h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    rows = torch.where(h >= 2 ** 31, h - 2 ** 32, h).to(torch.int32)
+    lens = torch.empty(N_IDS, dtype=torch.int32, device=dev)
+    m.rowlen_batch_dev(N_IDS, rows.data_ptr(), lens.data_ptr(), stream)
+    l64 = lens.to(torch.int64) & 0xFFFFFFFF
+    off = torch.zeros(N_IDS + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(l64 + 1, 0)                                       # rowlen + 1 pairs of room per row (quirk Q5)
+    total = int(off[-1].item())
+    ret = torch.empty((total, 2), dtype=torch.int32, device=dev)
+    cnt = torch.empty(N_IDS, dtype=torch.int32, device=dev)
+    best = 1e9
+    for _ in range(reps):
+        ret.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        m.getrow_batch_dev(N_IDS, rows.data_ptr(), off.data_ptr(), ret.data_ptr(), cnt.data_ptr(), stream)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    c64 = cnt.to(torch.int64) & 0xFFFFFFFF
+    pairs = int(c64.sum().item())
+    # rows are packed back to back only up to their count: everything past it inside a row's room stayed zero
+    vals = (ret[:, 1].to(torch.int64) & 0xFFFFFFFF).sum().item()
+    return {"rows": N_IDS, "pairs": pairs, "sum_of_values": int(vals), "max_row_pairs": int(c64.max().item()),
+            "counts_equal_rowlen": bool((c64 == l64).all().item()), "getrow_ms": best, "Gnnz_per_s": pairs / best / 1e6}
 
 
 def build_cf(torch, dev, m, rows, chunk_rows=1 << 17):
