@@ -44,6 +44,9 @@ def compare(tag):
         ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
         ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
         assert ka.shape == kb.shape and (ka == kb).all(), (tag, r, "cells")
+        ne = a[(a[:, 0] != 0) | (a[:, 1] != 0)]                  # getrow: the non-empty cells in slot order (big rows: segments)
+        got_row = np.asarray(g.getrow_raw(r, (g.getRowLength(r) + 1) * 8))
+        assert got_row.shape == ne.shape and (got_row == ne).all(), (tag, r, "getrow")
 
 
 ops = 0
