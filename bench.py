@@ -367,6 +367,60 @@ def scan_cf(torch, dev, m, rows, reps=5):
                                  "rule (src/smatrix.c:346), so the kernel has to MOVE table bytes + 8 B/nnz: moved_GBps_model"}}
 
 
+def cf_read_path(torch, dev, m, rows, reps=3):
+    """The reference's documented use of a matrix of this shape (examples/cf_recommender.c:50-86): column 0 of every row holds
+    the item's total; neighbors_for_item(a) = getrow(a) and, per neighbour b, get(b,0) and cc / (sqrt(total_a) sqrt(total_b)).
+    Here: the totals are added (one incr(x, 0, 115) per row), then smatrix_cf_neighbors_batch_dev scores ALL items in one call."""
+    from libsmatrix_amd import OP_INCR, OP_GET
+    stream = torch.cuda.current_stream().cuda_stream
+    xs = cf_row_ids(torch, dev, rows)
+    zeros = torch.zeros(rows, dtype=torch.int32, device=dev)
+    per = torch.full((rows,), CF_PER_ROW, dtype=torch.int32, device=dev)
+    m.apply_batch_dev(OP_INCR, rows, xs.data_ptr(), zeros.data_ptr(), per.data_ptr(), None, stream)
+    lens = torch.empty(rows, dtype=torch.int32, device=dev)
+    m.rowlen_batch_dev(rows, xs.data_ptr(), lens.data_ptr(), stream)
+    off = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens.long() + 2, 0, out=off[1:])              # the (0,total) cell is not in rowlen (quirk Q1): +1, and +1 spare
+    total = int(off[-1].item())
+    ids = torch.zeros(total, dtype=torch.int32, device=dev)
+    scores = torch.zeros(total, dtype=torch.float64, device=dev)
+    cnt = torch.empty(rows, dtype=torch.int32, device=dev)
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        m.cf_neighbors_batch_dev(rows, xs.data_ptr(), off.data_ptr(), ids.data_ptr(), scores.data_ptr(), cnt.data_ptr(), stream)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    nb = int(cnt.sum(dtype=torch.int64).item())
+    # check a sample of items against the same arithmetic in torch (float64, IEEE sqrt / multiply / divide: exact)
+    g = torch.Generator(device=dev); g.manual_seed(SEED + 1)
+    pick = torch.randint(0, rows, (20000,), device=dev, generator=g)
+    ok = True
+    a0 = off[pick]; c = cnt[pick].long()
+    idx = (a0.repeat_interleave(c) + (torch.arange(int(c.sum().item()), device=dev) - (torch.cumsum(c, 0) - c).repeat_interleave(c)))
+    nb_ids = ids[idx].contiguous(); nb_sc = scores[idx]
+    owner = xs[pick].repeat_interleave(c).contiguous()
+    n_s = nb_ids.numel()
+    cc = torch.empty(n_s, dtype=torch.int32, device=dev); tb = torch.empty_like(cc); ta = torch.empty_like(cc)
+    z = torch.zeros(n_s, dtype=torch.int32, device=dev)
+    m.apply_batch_dev(OP_GET, n_s, owner.data_ptr(), nb_ids.data_ptr(), None, cc.data_ptr(), stream)
+    m.apply_batch_dev(OP_GET, n_s, nb_ids.data_ptr(), z.data_ptr(), None, tb.data_ptr(), stream)
+    m.apply_batch_dev(OP_GET, n_s, owner.data_ptr(), z.data_ptr(), None, ta.data_ptr(), stream)
+    torch.cuda.synchronize()
+    u = lambda t: (t.long() & 0xFFFFFFFF).double()
+    tbf = torch.where(tb == 0, torch.ones_like(tb), tb)
+    den = torch.sqrt(u(ta)) * torch.sqrt(u(tbf)); num = u(cc)
+    want = torch.where((den == 0) | (num > den), torch.zeros_like(den), num / den)
+    ok = bool((want == nb_sc).all().item()) and nb == int(lens.sum(dtype=torch.int64).item()) + rows
+    sec = best * 1e-3
+    return {"items": rows, "neighbours": nb, "ms": best, "Gneighbours_per_s": nb / sec / 1e9, "Mitems_per_s": rows / sec / 1e6,
+            "verified_sample_items": int(pick.numel()), "verified": ok,
+            "random_touches_per_neighbour": 2,
+            "note": "per neighbour: its cell in the item's row (streamed), then get(b,0) = one directory slot + one cell at random; "
+                    "12 B out (id + double).  The per-item totals were added first with %d incr(x,0,115) ops (y = 0: quirk path)" % rows}
+
+
 def touch_hbm(torch, dev, nbytes):
     """First use of fresh HBM on a newly booted box is slow (the first 27 GB build of a process on a fresh box took 1.2 s,
     every later one 0.24 s -- driver-side first-touch work, not kernels): touch the amount once, outside any timing."""
@@ -396,6 +450,7 @@ def run_config3(torch, dev, rows=13000000, reps=5):
     res["build_first_s"] = build_first_s
     res["build_Gops_per_s"] = rows * CF_PER_ROW / build_s / 1e9
     res["workload"] = "config-3: smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz (CF shape), table built on the device" % (rows, res["nnz"])
+    res["cf_read_path"] = guarded(cf_read_path, torch, dev, m, rows)
     m.close()
     return res
 

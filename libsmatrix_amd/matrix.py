@@ -154,6 +154,9 @@ class SparseMatrix:
     def getrow_batch_dev(self, n, x_ptr, off_ptr, ret_ptr, cnt_ptr, stream=None):
         self._lib.smatrix_getrow_batch_dev(self._h, n, x_ptr, off_ptr, ret_ptr, cnt_ptr, stream)
 
+    def cf_neighbors_batch_dev(self, n, items_ptr, off_ptr, ids_ptr, scores_ptr, cnt_ptr, stream=None):
+        self._lib.smatrix_cf_neighbors_batch_dev(self._h, n, items_ptr, off_ptr, ids_ptr, scores_ptr, cnt_ptr, stream)
+
     # ---- introspection --------------------------------------------------------
     def stats(self):
         st = _lib.Stats()

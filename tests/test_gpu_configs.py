@@ -536,6 +536,24 @@ def _cf_full(rows, path, oracle_mod, torch):
     return nnz
 
 
+def test_cf_read_path_all_items_of_a_2m_row_matrix():
+    """examples/cf_recommender.c:50-86 at scale: totals in column 0 (y = 0, quirk Q1: not counted by rowlen), then every item's
+    neighbours scored by the fused kernel in ONE call; bench.cf_read_path re-derives 20 000 items' scores from get() results
+    with the example's arithmetic in float64 and demands equality, and neighbours == nnz + one (0,total) entry per row."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from libsmatrix_amd import SparseMatrix
+    dev = torch.device("cuda", 0)
+    rows = 2000000
+    m = SparseMatrix()
+    bench.build_cf(torch, dev, m, rows)
+    r = bench.cf_read_path(torch, dev, m, rows, reps=1)
+    assert r["verified"] and r["items"] == rows
+    assert rows * (bench.CF_PER_ROW + 1) * 0.9995 <= r["neighbours"] <= rows * (bench.CF_PER_ROW + 1)
+    m.close()
+
+
 def test_config3_and_5_full_scale_13m_rows(oracle_mod, tmp_path):
     """BASELINE config 3 at full size on one GPU -- 13 M rows / 1.495 G nnz / 27 GB of row tables, built on the
     device -- checked through size-independent properties (sum rowlen == pairs getrow returns, values sum to the
