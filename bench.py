@@ -421,6 +421,37 @@ def cf_read_path(torch, dev, m, rows, reps=3):
                     "12 B out (id + double).  The per-item totals were added first with %d incr(x,0,115) ops (y = 0: quirk path)" % rows}
 
 
+def cf_write_path(torch, dev, sessions=1 << 20, L=12):
+    """examples/cf_recommender.c:36-47 on the device: `sessions` sessions of L item ids (Zipf(1.1) over 1 M scrambled ids, the
+    config-2 marginal) -> L*L incr ops each, generated and applied by smatrix_cf_import_sessions_dev"""
+    from libsmatrix_amd import SparseMatrix, Stream, OP_GET
+    stream = torch.cuda.current_stream().cuda_stream
+    n_ids = sessions * L
+    gen = Stream("zipf", SEED + 7, N_IDS, ZIPF_S, 1)
+    ids = torch.empty(n_ids, dtype=torch.int32, device=dev); scratch = torch.empty_like(ids)
+    gen.fill_device(0, n_ids, ids.data_ptr(), scratch.data_ptr(), stream)
+    off = torch.arange(0, sessions + 1, dtype=torch.int64, device=dev) * L
+    op_off = torch.arange(0, sessions + 1, dtype=torch.int64, device=dev) * (L * L)
+    total = sessions * L * L
+    m = SparseMatrix()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.cf_import_sessions_dev(sessions, off.data_ptr(), ids.data_ptr(), op_off.data_ptr(), total, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # every position of every session added 1 to its item's total in column 0
+    items = torch.unique(ids)
+    z = torch.zeros_like(items); tot = torch.empty_like(items)
+    m.apply_batch_dev(OP_GET, items.numel(), items.data_ptr(), z.data_ptr(), None, tot.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = m.stats()
+    ok = int((tot.long() & 0xFFFFFFFF).sum().item()) == n_ids and int(st["rows"]) == items.numel()
+    m.close(); gen.close()
+    return {"sessions": sessions, "ids_per_session": L, "incr_ops": total, "seconds": dt, "Gops_per_s": total / dt / 1e9,
+            "items": int(items.numel()), "verified_totals": ok,
+            "note": "first import into an empty matrix (rows are created and grown on the way)"}
+
+
 def touch_hbm(torch, dev, nbytes):
     """First use of fresh HBM on a newly booted box is slow (the first 27 GB build of a process on a fresh box took 1.2 s,
     every later one 0.24 s -- driver-side first-touch work, not kernels): touch the amount once, outside any timing."""
@@ -452,6 +483,7 @@ def run_config3(torch, dev, rows=13000000, reps=5):
     res["workload"] = "config-3: smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz (CF shape), table built on the device" % (rows, res["nnz"])
     res["cf_read_path"] = guarded(cf_read_path, torch, dev, m, rows)
     m.close()
+    res["cf_write_path"] = guarded(cf_write_path, torch, dev)
     return res
 
 

@@ -83,6 +83,16 @@ int smatrix_cf_neighbors_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_
                                    const uint64_t* d_offsets, uint32_t* d_ids, double* d_scores,
                                    uint32_t* d_counts, void* hip_stream);
 
+/* CF-recommender write path, on the device (examples/cf_recommender.c:36-47 import_preference_set): session s is
+ * ids[offsets[s] .. offsets[s+1]); for every position n of a session  incr(ids[n], 0, 1)  and, for every OTHER position i,
+ * incr(ids[n], ids[i], 1) -- L*L ops for a session of L ids, generated on the GPU and applied as incr batches (the
+ * batch contract above: any order, same final state).  offsets has n_sessions+1 entries.
+ * _dev: all arrays in device memory; d_op_offsets[s] = sum of L*L over the sessions before s (n_sessions+1 entries),
+ * total_ops = its last entry. */
+int smatrix_cf_import_sessions(smatrix_t* self, size_t n_sessions, const uint64_t* offsets, const uint32_t* ids);
+int smatrix_cf_import_sessions_dev(smatrix_t* self, size_t n_sessions, const uint64_t* d_offsets, const uint32_t* d_ids,
+                                   const uint64_t* d_op_offsets, uint64_t total_ops, void* hip_stream);
+
 /* ---- introspection (tests, bench) ---------------------------------------- */
 typedef struct {
   uint64_t rows;            /* rows in the directory */

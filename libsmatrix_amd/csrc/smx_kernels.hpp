@@ -369,8 +369,11 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
     // field is 0 -- the row's own (0,v) entry or the first empty slot -- is a hit;
     // nothing is inserted and `used` is not touched.  Done with a 64-bit CAS so
     // that a concurrent claim of that empty slot by another key cannot be hit.
+    // (the guard counts CELLS walked, not attempts: a CAS lost to another writer of the same cell -- every item's total
+    //  lives in column 0 in the CF example, and a hot item's is written from hundreds of workgroups at once -- is retried
+    //  on the value it returned and must never end the loop: somebody else made progress)
     uint64_t c = ld_relaxed(&cells[pos]);
-    for (uint32_t guard = 0; guard < 4u * (mask + 1u); guard++) {
+    for (uint32_t guard = 0; guard < 4u * (mask + 1u);) {
       if (cell_key(c) == 0) {
         uint32_t nv = OP == OP_INCR ? cell_val(c) + V : OP == OP_DECR ? cell_val(c) - V : V;
         uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]),
@@ -379,6 +382,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         c = prev;
         continue;
       }
+      guard++;
       pos = (pos + 1) & mask;
       c = ld_relaxed(&cells[pos]);
     }
@@ -488,7 +492,7 @@ __global__ void k_scalar(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t 
 //            (directory lookup, probe, claim, ONE global atomic) and leaves the cell's old value
 //   phase 3  every op returns  old + prefix + v  (incr)  /  old - prefix - v  (decr)
 // -- the values a serial execution of the tile's ops in LDS-arrival order returns, i.e. a legal
-// serialisation.  Keys with y == 0 (quirk path) and the all-ones key take the per-op body.
+// serialisation.  The all-ones key (the LDS table's empty marker) takes the per-op body.
 #ifndef SMX_AGG_PATIENT
 #define SMX_AGG_PATIENT true
 #endif
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
     const uint32_t X = xs[(size_t)j[k] * ST], Y = ys[(size_t)j[k] * ST];
     V[k] = vs[(size_t)j[k] * ST];
     const uint64_t key = (uint64_t)X | ((uint64_t)Y << 32);
-    if (Y == 0 || key == ~0ull) { slot[k] = ~0u - 1; continue; }
+    if (key == ~0ull) { slot[k] = ~0u - 1; continue; }      // the LDS table's empty marker: per-op path
     uint32_t h = (X * 0x9E3779B1u) ^ (Y * 0x85EBCA77u);
     h = (h ^ (h >> 15)) & (AGG_SLOTS - 1);
     for (;;) {
@@ -592,7 +596,10 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
 #pragma unroll
     for (uint32_t q = 0; q < AGG_OPT; q++) {
       if (!(have & (1u << q))) continue;
-      if ((ds[q].x & META_USED) && ds[q].y == (uint32_t)kk[q] && ds[q].z != 0) {
+      // (y == 0 is folded like any key -- the CF example keeps every item's total there, examples/cf_recommender.c:38 --
+      //  but never takes this pipelined path: its cell is found and updated by the quirk branch of the per-op body,
+      //  with a 64-bit CAS, because "the first slot whose key field is 0" may be an empty slot another key is claiming)
+      if ((ds[q].x & META_USED) && ds[q].y == (uint32_t)kk[q] && ds[q].z != 0 && (uint32_t)(kk[q] >> 32) != 0) {
         const uint32_t Y = (uint32_t)(kk[q] >> 32);
         cp[q] = row_cells(arena, ds[q].z) + (Y & ((1u << meta_lg(ds[q].x)) - 1u));
         cc[q] = *cp[q];
@@ -2187,6 +2194,26 @@ __global__ __launch_bounds__(256) void k_cf_neighbors(DirSlot* dir, uint32_t dma
     }
     if (lane == 0) counts[r] = written;
   }
+}
+
+// ---- CF-recommender write path (examples/cf_recommender.c:36-47) ------------------------------------------
+// A session of L ids is L*L incr ops: op r of the session has n = r / L, i = r % L and is (ids[n], 0, +1) when i == n,
+// (ids[n], ids[i], +1) otherwise.  op_off[s] = sum of L*L over the sessions before s.  One lane per op of the range
+// [t0, t0 + count): a binary search for its session, then the pair.
+__global__ __launch_bounds__(256) void k_cf_expand(uint64_t t0, uint32_t count, uint32_t n_sessions,
+                                                   const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ ids,
+                                                   const uint64_t* __restrict__ op_off,
+                                                   uint32_t* __restrict__ xs, uint32_t* __restrict__ ys, uint32_t* __restrict__ vs) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  const uint64_t t = t0 + k;
+  uint32_t lo = 0, hi = n_sessions;                      // the last session with op_off[s] <= t
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (op_off[mid] <= t) lo = mid; else hi = mid; }
+  const uint64_t first = offsets[lo], L = offsets[lo + 1] - first, r = t - op_off[lo];
+  const uint64_t n = r / L, i = r - n * L;
+  xs[k] = ids[first + n];
+  ys[k] = i == n ? 0u : ids[first + i];
+  vs[k] = 1u;
 }
 
 // ---- persistence: dirty rows (src/smatrix.c:418-425 rmap_sync_defer, :929-960 the IO thread's queue) --------

@@ -1365,6 +1365,60 @@ uint32_t smatrix_getrow(smatrix_t* self, uint32_t x, uint32_t* ret, size_t ret_l
   return count;
 }
 
+// ---- CF-recommender write path (examples/cf_recommender.c:36-47) ------------------------------------------------
+// n_sessions sessions, session s = ids[offsets[s] .. offsets[s+1]); d_op_offsets[s] = sum of L*L over the sessions before s
+// (n_sessions + 1 entries, the last one = total_ops).  The L*L incr ops of every session are generated on the device in
+// chunks of CF_IMPORT_CHUNK ops and applied as ordinary incr batches.
+static constexpr uint64_t CF_IMPORT_CHUNK = 1ull << 25;
+int smatrix_cf_import_sessions_dev(smatrix_t* self, size_t n_sessions, const uint64_t* d_offsets, const uint32_t* d_ids,
+                                   const uint64_t* d_op_offsets, uint64_t total_ops, void* hip_stream) {
+  if (n_sessions == 0 || total_ops == 0) return 0;
+  if (n_sessions > 0xffffffffull) return -1;
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, true);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
+  const size_t chunk = (size_t)std::min<uint64_t>(total_ops, CF_IMPORT_CHUNK);
+  m->sx.need(chunk); m->sy.need(chunk); m->sv.need(chunk); m->so.need(chunk);
+  for (uint64_t t0 = 0; t0 < total_ops; t0 += CF_IMPORT_CHUNK) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(CF_IMPORT_CHUNK, total_ops - t0);
+    hipLaunchKernelGGL(k_cf_expand, dim3(blocks_for(n)), dim3(256), 0, s, t0, n, (uint32_t)n_sessions, d_offsets, d_ids,
+                       d_op_offsets, m->sx.p, m->sy.p, m->sv.p);
+    HIP_OK(hipGetLastError());
+    apply_dev_locked(self, OP_INCR, n, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);
+  }
+  if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int smatrix_cf_import_sessions(smatrix_t* self, size_t n_sessions, const uint64_t* offsets, const uint32_t* ids) {
+  if (n_sessions == 0) return 0;
+  Matrix* m = M(self);
+  set_device(m);
+  std::vector<uint64_t> op_off(n_sessions + 1, 0);
+  for (size_t i = 0; i < n_sessions; i++) {
+    if (offsets[i + 1] < offsets[i]) return -1;
+    const uint64_t L = offsets[i + 1] - offsets[i];
+    op_off[i + 1] = op_off[i] + L * L;
+  }
+  const uint64_t n_ids = offsets[n_sessions] - offsets[0], total = op_off[n_sessions];
+  if (total == 0) return 0;
+  uint64_t *d_off = nullptr, *d_op = nullptr;
+  uint32_t* d_ids = nullptr;
+  HIP_OK(hipMalloc(&d_off, (n_sessions + 1) * 8));
+  HIP_OK(hipMalloc(&d_op, (n_sessions + 1) * 8));
+  HIP_OK(hipMalloc(&d_ids, std::max<uint64_t>(n_ids, 1) * 4));
+  std::vector<uint64_t> rel(n_sessions + 1);
+  for (size_t i = 0; i <= n_sessions; i++) rel[i] = offsets[i] - offsets[0];
+  HIP_OK(hipMemcpy(d_off, rel.data(), (n_sessions + 1) * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_op, op_off.data(), (n_sessions + 1) * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_ids, ids + offsets[0], n_ids * 4, hipMemcpyHostToDevice));
+  const int rc = smatrix_cf_import_sessions_dev(self, n_sessions, d_off, d_ids, d_op, total, nullptr);
+  (void)hipFree(d_off); (void)hipFree(d_op); (void)hipFree(d_ids);
+  return rc;
+}
+
 // ---- introspection -------------------------------------------------------------------
 void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   Matrix* m = M(self);

@@ -139,6 +139,19 @@ class SparseMatrix:
                                              _p(ids), scores.ctypes.data_as(C.POINTER(C.c_double)), _p(counts))
         return offsets, ids, scores, counts
 
+    def cf_import_sessions(self, sessions):
+        """CF-recommender write path (examples/cf_recommender.c:36-47): every session is a sequence of item ids; all
+        their L*L incr ops are generated and applied on the GPU"""
+        lens = np.array([len(s) for s in sessions], dtype=np.uint64)
+        offsets = np.zeros(len(sessions) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:])
+        ids = _u32(np.concatenate([np.asarray(s, dtype=np.uint32) for s in sessions]) if len(sessions) else np.zeros(0, np.uint32))
+        if self._lib.smatrix_cf_import_sessions(self._h, len(sessions), offsets.ctypes.data_as(_lib.u64p), _p(ids)) != 0:
+            raise ValueError("smatrix_cf_import_sessions")
+
+    def cf_import_sessions_dev(self, n_sessions, off_ptr, ids_ptr, op_off_ptr, total_ops, stream=None):
+        self._lib.smatrix_cf_import_sessions_dev(self._h, n_sessions, off_ptr, ids_ptr, op_off_ptr, total_ops, stream)
+
     # device-pointer flavours (raw pointers; stream = hipStream_t as int or None)
     def apply_batch_dev(self, op, n, x_ptr, y_ptr, v_ptr, out_ptr, stream=None):
         self._lib.smatrix_apply_batch_dev(self._h, op, n, x_ptr, y_ptr, v_ptr, out_ptr, stream)

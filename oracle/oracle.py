@@ -192,6 +192,15 @@ def cf_neighbors(oracle_handle, item, cap):
     return ids[:n], sc[:n]
 
 
+def cf_import_preference_set(oracle_handle, ids):
+    """ora_cf_import_preference_set on an Oracle instance (examples/cf_recommender.c:36-47)"""
+    fn = oracle_handle._lib.ora_cf_import_preference_set
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, _u32p, C.c_uint32]
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    fn(oracle_handle._h, _ptr(ids), ids.size)
+
+
 def Reference(fname=None):
     if "r" not in _cache:
         if not have_reference():

@@ -457,6 +457,18 @@ uint32_t ora_cf_neighbors(ora_matrix_t* m, uint32_t item, uint32_t* ids, double*
   return n;
 }
 
+/* examples/cf_recommender.c:36-47 import_preference_set: for every position n of the session
+ *   incr(ids[n], 0, 1)  and, for every OTHER position i, incr(ids[n], ids[i], 1)
+ * (the example loops `i < pset->len` with an undeclared pset; the evident intent is the session itself).  The test is on
+ * POSITIONS (i != n), so an id that occurs twice in a session also counts itself. */
+void ora_cf_import_preference_set(ora_matrix_t* m, const uint32_t* ids, uint32_t num_ids) {
+  for (uint32_t n = 0; n < num_ids; n++) {
+    ora_incr(m, ids[n], 0, 1);
+    for (uint32_t i = 0; i < num_ids; i++)
+      if (i != n) ora_incr(m, ids[n], ids[i], 1);
+  }
+}
+
 uint64_t ora_num_rows(ora_matrix_t* m) { return m->dir_used; }
 uint64_t ora_dir_size(ora_matrix_t* m) { return m->dir_size; }
 uint64_t ora_mem(ora_matrix_t* m) { return m->mem; }

@@ -54,6 +54,8 @@ uint64_t ora_sum_get(ora_matrix_t* m, size_t n, const uint32_t* x, const uint32_
 /* CF-recommender read path as the example intends it (examples/cf_recommender.c:50-86): neighbours of
  * `item` in getrow (slot) order with their cosine scores; returns the count (<= cap) */
 uint32_t ora_cf_neighbors(ora_matrix_t* m, uint32_t item, uint32_t* ids, double* scores, uint32_t cap);
+/* examples/cf_recommender.c:36-47 */
+void ora_cf_import_preference_set(ora_matrix_t* m, const uint32_t* ids, uint32_t num_ids);
 
 /* introspection: row table geometry and raw slots (slot order) */
 uint64_t ora_num_rows(ora_matrix_t* m);              /* cmap.used  */

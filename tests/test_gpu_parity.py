@@ -755,6 +755,61 @@ def test_cf_recommender_read_path(G, oracle_mod):
     g.close(); o.close()
 
 
+def test_column_zero_totals_under_contention(G):
+    """every item's total lives in column 0 in the CF example (examples/cf_recommender.c:38): millions of incr(x, 0, 1) on a few
+    hot items, mixed with inserts into the same rows (the (0,v) cell is found by probing for 'key field 0', which an empty
+    slot another key is claiming also satisfies).  No update may be lost: the totals are exact."""
+    rng = np.random.default_rng(77)
+    n = 1 << 22
+    x = rng.choice(np.array([5, 6, 7, 1000003], np.uint32), n, p=[0.7, 0.2, 0.09, 0.01]).astype(np.uint32)
+    y = np.where(rng.random(n) < 0.8, 0, rng.integers(1, 50000, n)).astype(np.uint32)
+    g = G()
+    for a in range(0, n, 1 << 20):                       # four batches: the rows grow in between
+        g.apply(2, x[a:a + (1 << 20)], y[a:a + (1 << 20)], np.ones(1 << 20, np.uint32))
+    for item in (5, 6, 7, 1000003):
+        assert g.get(item, 0) == int(((x == item) & (y == 0)).sum()), item
+    k = (x.astype(np.uint64) << 32 | y)[y != 0]
+    uk, cnt = np.unique(k, return_counts=True)
+    got = g.apply(0, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32))
+    assert (got == cnt).all()
+    g.close()
+
+
+def test_cf_recommender_write_path_on_device(G, oracle_mod):
+    """examples/cf_recommender.c:36-47 import_preference_set, expanded on the GPU (smatrix_cf_import_sessions: L*L incr ops
+    per session of L ids) against the oracle's restatement called session by session: every row holds the same cells
+    (the (0,total) cell included), every get agrees, and the read path scores agree.  Sessions: empty, one id, an id
+    twice (the example tests POSITIONS i != n, so the id then counts itself), up to 40 ids.  rowlen itself is not
+    compared: with y = 0 in a row it depends on WHEN the row last grew (quirk Q2), and a batch is one legal order."""
+    rng = np.random.default_rng(31)
+    sessions = [[], [7], [9, 9], [3, 5, 3]]
+    for _ in range(3000):
+        L = int(rng.integers(0, 13))
+        sessions.append((rng.integers(1, 400, L)).tolist())
+    sessions.append((rng.choice(5000, 40, replace=False) + 1000).tolist())
+    g, o = G(), oracle_mod.Oracle()
+    g.m.cf_import_sessions(sessions)
+    for s_ in sessions:
+        oracle_mod.cf_import_preference_set(o, s_)
+    rows = o.list_rows()
+    assert g.stats()["rows"] == rows.size
+    for r in rows.tolist():
+        a, b = np.asarray(g.row_slots(r)), np.asarray(o.row_slots(r))
+        ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
+        ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
+        assert ka.shape == kb.shape and (ka == kb).all(), r
+    for a_, b_ in ((9, 9), (9, 0), (3, 3), (3, 5), (5, 3), (7, 0), (1039, 0)):
+        assert g.get(a_, b_) == o.get(a_, b_), (a_, b_)
+    assert o.get(9, 9) >= 2 and o.get(3, 3) >= 2                      # the repeated id counted itself
+    items = rows[:300]
+    off, ids, sc, cnt = g.m.cf_neighbors_batch(items)
+    for i, it in enumerate(items.tolist()):
+        wi, ws = oracle_mod.cf_neighbors(o, it, 100000)
+        mine = dict(zip(ids[off[i]: off[i] + cnt[i]].tolist(), sc[off[i]: off[i] + cnt[i]].tolist()))
+        assert mine == dict(zip(wi.tolist(), ws.tolist())), it
+    g.close(); o.close()
+
+
 def test_sharded_pipeline_matches_direct():
     """split-phase ShardedMatrix with its own communication stream (the form bench.py pipelines at N>1)
     against the direct path, one rank over RCCL: identical get results and per-key incr returns"""
