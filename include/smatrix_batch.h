@@ -83,6 +83,15 @@ int smatrix_cf_neighbors_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_
                                    const uint64_t* d_offsets, uint32_t* d_ids, double* d_scores,
                                    uint32_t* d_counts, void* hip_stream);
 
+/* The same read path, but only the k <= 64 BEST neighbours of each item leave the GPU (what a recommender serves):
+ * best score first, equal scores in table slot order; the candidates and the score are exactly those above (the
+ * (0,total) entry of the row included, as in the example's loop).  ids / scores hold n*k entries, item i's at
+ * [i*k, i*k + counts[i]); counts[i] = min(k, entries of the row).  Returns -1 for k == 0 or k > 64. */
+int smatrix_cf_topk_batch(smatrix_t* self, size_t n, const uint32_t* items, uint32_t k, uint32_t* ids, double* scores,
+                          uint32_t* counts);
+int smatrix_cf_topk_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_items, uint32_t k, uint32_t* d_ids,
+                              double* d_scores, uint32_t* d_counts, void* hip_stream);
+
 /* CF-recommender write path, on the device (examples/cf_recommender.c:36-47 import_preference_set): session s is
  * ids[offsets[s] .. offsets[s+1]); for every position n of a session  incr(ids[n], 0, 1)  and, for every OTHER position i,
  * incr(ids[n], ids[i], 1) -- L*L ops for a session of L ids, generated on the GPU and applied as incr batches (the

@@ -2196,6 +2196,102 @@ __global__ __launch_bounds__(256) void k_cf_neighbors(DirSlot* dir, uint32_t dma
   }
 }
 
+// ---- CF-recommender read path, the k best neighbours only ---------------------------------------------------
+// Same candidates and the same score as k_cf_neighbors (every entry the example's loop would print, the (0,total) entry
+// included), but only the k <= 64 best per item leave the kernel: best score first, equal scores in table slot order.
+// One wave per item; lane i holds the i-th best so far.  Per 64 cells: the candidates are sorted across the wave (bitonic,
+// shuffles only), merged with the running list (the better of A[i] and B[63-i] is a bitonic sequence of the best 64 of
+// both; six more stages sort it), and a step none of whose candidates beats the current k-th is skipped -- which is
+// nearly every step of a long row.
+struct CfCand {
+  long long key;      // the score's bit pattern (scores are >= 0: ordered like signed integers); LLONG_MIN = no candidate
+  uint32_t slot, id;
+};
+__device__ __forceinline__ bool cf_better(const CfCand& a, const CfCand& b) {
+  return a.key > b.key || (a.key == b.key && a.slot < b.slot);
+}
+__device__ __forceinline__ CfCand cf_shfl_xor(const CfCand& v, int j) {
+  CfCand o;
+  o.key = ((long long)__shfl_xor((int)(v.key >> 32), j) << 32) | (uint32_t)__shfl_xor((int)v.key, j);
+  o.slot = (uint32_t)__shfl_xor((int)v.slot, j);
+  o.id = (uint32_t)__shfl_xor((int)v.id, j);
+  return o;
+}
+__device__ __forceinline__ CfCand cf_shfl(const CfCand& v, int src) {
+  CfCand o;
+  o.key = ((long long)__shfl((int)(v.key >> 32), src) << 32) | (uint32_t)__shfl((int)v.key, src);
+  o.slot = (uint32_t)__shfl((int)v.slot, src);
+  o.id = (uint32_t)__shfl((int)v.id, src);
+  return o;
+}
+// stages j = from, from/2, .. 1 of a bitonic network over the wave's 64 lanes, best first
+__device__ __forceinline__ void cf_merge_stages(CfCand& v, uint32_t lane, uint32_t from) {
+  for (uint32_t j = from; j; j >>= 1) {
+    const CfCand o = cf_shfl_xor(v, (int)j);
+    const bool want_better = (lane & j) == 0;              // the lower lane of a pair keeps the better one
+    if (cf_better(o, v) == want_better) v = o;
+  }
+}
+__device__ __forceinline__ void cf_sort64(CfCand& v, uint32_t lane) {
+  for (uint32_t k2 = 2; k2 <= 64; k2 <<= 1) {
+    for (uint32_t j = k2 >> 1; j; j >>= 1) {
+      const CfCand o = cf_shfl_xor(v, (int)j);
+      const bool down = (lane & k2) == 0 || k2 == 64;     // blocks alternate direction; the last pass is best-first
+      const bool want_better = ((lane & j) == 0) == down;
+      if (cf_better(o, v) == want_better) v = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cf_topk(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n,
+                                                 const uint32_t* __restrict__ items, uint32_t k,
+                                                 uint32_t* __restrict__ ids, double* __restrict__ scores,
+                                                 uint32_t* __restrict__ counts) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  constexpr long long NONE = (long long)0x8000000000000000ull;
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    uint4 s;
+    DirSlot* d = dir_find(dir, dmask, items[r], &s);
+    CfCand top{NONE, 0xffffffffu, 0u};
+    if (d && s.z != 0) {
+      bool dummy = false;
+      const uint32_t a_total = apply_one<OP_GET>(dir, dmask, arena, items[r], 0u, 0u, &dummy);
+      const double sa = sqrt((double)a_total);
+      const uint32_t size = 1u << meta_lg(s.x);
+      const uint64_t* cells = row_cells(arena, s.z);
+      for (uint32_t p0 = 0; p0 < size; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const uint64_t c = p < size ? cells[p] : 0;
+        CfCand cand{NONE, p, cell_key(c)};
+        if (c != 0) {
+          uint32_t b_total = apply_one<OP_GET>(dir, dmask, arena, cell_key(c), 0u, 0u, &dummy);
+          if (b_total == 0) b_total = 1;
+          const double num = (double)cell_val(c);
+          const double den = sa * sqrt((double)b_total);
+          double score = 0.0;
+          if (den != 0.0 && !(num > den)) score = num / den;
+          cand.key = __double_as_longlong(score);
+        }
+        const CfCand kth = cf_shfl(top, (int)k - 1);
+        if (!__any(cand.key != NONE && cf_better(cand, kth))) continue;
+        cf_sort64(cand, lane);
+        const CfCand rev = cf_shfl(cand, 63 - (int)lane);
+        if (cf_better(rev, top)) top = rev;
+        cf_merge_stages(top, lane, 32);
+      }
+    }
+    const bool have = lane < k && top.key != NONE;
+    if (have) {
+      ids[(uint64_t)r * k + lane] = top.id;
+      scores[(uint64_t)r * k + lane] = __longlong_as_double(top.key);
+    }
+    const uint64_t m = __ballot(have);
+    if (lane == 0) counts[r] = (uint32_t)__popcll(m);
+  }
+}
+
 // ---- CF-recommender write path (examples/cf_recommender.c:36-47) ------------------------------------------
 // A session of L ids is L*L incr ops: op r of the session has n = r / L, i = r % L and is (ids[n], 0, +1) when i == n,
 // (ids[n], ids[i], +1) otherwise.  op_off[s] = sum of L*L over the sessions before s.  One lane per op of the range

@@ -1365,6 +1365,47 @@ uint32_t smatrix_getrow(smatrix_t* self, uint32_t x, uint32_t* ret, size_t ret_l
   return count;
 }
 
+// the k best neighbours per item (k <= 64); ids / scores hold n * k entries, item i's at [i*k, i*k + counts[i])
+int smatrix_cf_topk_batch_dev(smatrix_t* self, size_t n, const uint32_t* d_items, uint32_t k, uint32_t* d_ids,
+                              double* d_scores, uint32_t* d_counts, void* hip_stream) {
+  if (k == 0 || k > 64) return -1;
+  if (n == 0) return 0;
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  cache_sync(m, false);
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
+  uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
+  hipLaunchKernelGGL(k_cf_topk, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, (uint32_t)n, d_items, k,
+                     d_ids, d_scores, d_counts);
+  HIP_OK(hipGetLastError());
+  if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int smatrix_cf_topk_batch(smatrix_t* self, size_t n, const uint32_t* items, uint32_t k, uint32_t* ids, double* scores,
+                          uint32_t* counts) {
+  if (k == 0 || k > 64) return -1;
+  if (n == 0) return 0;
+  Matrix* m = M(self);
+  set_device(m);
+  uint32_t *d_items = nullptr, *d_ids = nullptr, *d_counts = nullptr;
+  double* d_scores = nullptr;
+  HIP_OK(hipMalloc(&d_items, n * 4));
+  HIP_OK(hipMalloc(&d_counts, n * 4));
+  HIP_OK(hipMalloc(&d_ids, n * k * 4));
+  HIP_OK(hipMalloc(&d_scores, n * k * 8));
+  HIP_OK(hipMemset(d_ids, 0, n * k * 4));
+  HIP_OK(hipMemset(d_scores, 0, n * k * 8));
+  HIP_OK(hipMemcpy(d_items, items, n * 4, hipMemcpyHostToDevice));
+  smatrix_cf_topk_batch_dev(self, n, d_items, k, d_ids, d_scores, d_counts, nullptr);
+  HIP_OK(hipMemcpy(counts, d_counts, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(ids, d_ids, n * k * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(scores, d_scores, n * k * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d_items); (void)hipFree(d_counts); (void)hipFree(d_ids); (void)hipFree(d_scores);
+  return 0;
+}
+
 // ---- CF-recommender write path (examples/cf_recommender.c:36-47) ------------------------------------------------
 // n_sessions sessions, session s = ids[offsets[s] .. offsets[s+1]); d_op_offsets[s] = sum of L*L over the sessions before s
 // (n_sessions + 1 entries, the last one = total_ops).  The L*L incr ops of every session are generated on the device in

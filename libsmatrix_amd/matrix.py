@@ -139,6 +139,20 @@ class SparseMatrix:
                                              _p(ids), scores.ctypes.data_as(C.POINTER(C.c_double)), _p(counts))
         return offsets, ids, scores, counts
 
+    def cf_topk_batch(self, items, k):
+        """the k best neighbours per item (k <= 64): -> (ids[n,k], scores[n,k] float64, counts[n])"""
+        items = _u32(items)
+        ids = np.zeros((items.size, k), dtype=np.uint32)
+        scores = np.zeros((items.size, k), dtype=np.float64)
+        counts = np.zeros(items.size, dtype=np.uint32)
+        if self._lib.smatrix_cf_topk_batch(self._h, items.size, _p(items), k, ids.ctypes.data_as(_lib.u32p),
+                                           scores.ctypes.data_as(C.POINTER(C.c_double)), _p(counts)) != 0:
+            raise ValueError("k must be 1..64")
+        return ids, scores, counts
+
+    def cf_topk_batch_dev(self, n, items_ptr, k, ids_ptr, scores_ptr, cnt_ptr, stream=None):
+        self._lib.smatrix_cf_topk_batch_dev(self._h, n, items_ptr, k, ids_ptr, scores_ptr, cnt_ptr, stream)
+
     def cf_import_sessions(self, sessions):
         """CF-recommender write path (examples/cf_recommender.c:36-47): every session is a sequence of item ids; all
         their L*L incr ops are generated and applied on the GPU"""

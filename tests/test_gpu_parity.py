@@ -755,6 +755,63 @@ def test_cf_recommender_read_path(G, oracle_mod):
     g.close(); o.close()
 
 
+def test_cf_topk(G, oracle_mod):
+    """the k best neighbours per item (smatrix_cf_topk_batch) against the oracle's full neighbour list ordered by
+    (score descending, table position ascending).  First a matrix built ONE OP PER CALL, whose tables are byte-identical
+    to the oracle's, so that ties must come out in the same order; then a batch-built one (layouts may differ: scores
+    exact, every returned id carries the oracle's score for it, nothing better was left out)."""
+    rng = np.random.default_rng(12)
+
+    def expected(o, it, k):
+        wi, ws = oracle_mod.cf_neighbors(o, it, 1 << 20)
+        order = np.lexsort((np.arange(wi.size), -ws))[:k]
+        return wi, ws, order
+
+    # (a) identical layouts: scalar calls
+    g, o = G(), oracle_mod.Oracle()
+    for _ in range(120):
+        ids = rng.choice(40, size=int(rng.integers(2, 7)), replace=False) + 1
+        for a in ids.tolist():
+            g.incr(a, 0, 1); o.incr(a, 0, 1)
+            for b in ids.tolist():
+                if a != b:
+                    g.incr(a, b, 1); o.incr(a, b, 1)
+    items = np.arange(0, 45, dtype=np.uint32)
+    for k in (1, 3, 10, 64):
+        ids_k, sc_k, cnt = g.m.cf_topk_batch(items, k)
+        for i, it in enumerate(items.tolist()):
+            wi, ws, order = expected(o, it, k)
+            assert cnt[i] == order.size, (k, it)
+            assert ids_k[i, :cnt[i]].tolist() == wi[order].tolist(), (k, it)
+            assert sc_k[i, :cnt[i]].tolist() == ws[order].tolist(), (k, it)
+    with pytest.raises(ValueError):
+        g.m.cf_topk_batch(items, 65)
+    g.close(); o.close()
+    # (b) batch-built, rows of up to ~600 entries (several 64-cell steps, merges and skipped steps)
+    xs, ys = [], []
+    for _ in range(6000):
+        ids = rng.choice(900, size=int(rng.integers(2, 12)), replace=False) + 1
+        for a in ids:
+            xs.append(a); ys.append(0)
+            for b in ids:
+                if a != b:
+                    xs.append(a); ys.append(b)
+    x, y = np.array(xs, np.uint32), np.array(ys, np.uint32)
+    g, o = G(), oracle_mod.Oracle()
+    g.apply(2, x, y, np.ones_like(x)); o.apply(2, x, y, np.ones_like(x))
+    items = np.arange(0, 920, dtype=np.uint32)
+    for k in (5, 64):
+        ids_k, sc_k, cnt = g.m.cf_topk_batch(items, k)
+        for i, it in enumerate(items.tolist()):
+            wi, ws, order = expected(o, it, k)
+            assert cnt[i] == order.size
+            assert sc_k[i, :cnt[i]].tolist() == ws[order].tolist(), (k, it)
+            score_of = dict(zip(wi.tolist(), ws.tolist()))
+            assert all(score_of[a] == b for a, b in zip(ids_k[i, :cnt[i]].tolist(), sc_k[i, :cnt[i]].tolist())), (k, it)
+            assert len(set(ids_k[i, :cnt[i]].tolist())) == cnt[i]
+    g.close(); o.close()
+
+
 def test_column_zero_totals_under_contention(G):
     """every item's total lives in column 0 in the CF example (examples/cf_recommender.c:38): millions of incr(x, 0, 1) on a few
     hot items, mixed with inserts into the same rows (the (0,v) cell is found by probing for 'key field 0', which an empty
