@@ -298,7 +298,7 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
 //           at the slot it found)
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
-                                     bool* deferred, LongProbe* lp, bool dbg_noticket = false) {
+                                     bool* deferred, LongProbe* lp, bool dbg_noticket = false, bool no_ret = false) {
   uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
@@ -374,6 +374,21 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
     //  on the value it returned and must never end the loop: somebody else made progress)
     uint64_t c = ld_relaxed(&cells[pos]);
     for (uint32_t guard = 0; guard < 4u * (mask + 1u);) {
+      if (OP != OP_SET && no_ret && cell_key(c) == 0) {
+        // The caller does not want the op's result (d_out == NULL; the CF import): ONE 64-bit add of V << 32 to the whole
+        // cell instead of the CAS loop.  A hot item's total is written from every tile of a batch, and each lost CAS is
+        // another trip to the same address: 24 ms per 2^25-op batch of the session import against 3 ms like this.
+        // The add lands in the value half whatever the key half is by then: key still 0 -> done (an empty cell has just
+        // become the row's (0,v) entry, exactly quirk Q1); key != 0 -> another key claimed the cell in between, the add
+        // is taken back and the walk goes on.  The table's final state is exact either way; only a RESULT read from
+        // that other key's cell during the few hundred ns in between would be off -- which is why this path exists for
+        // callers without results only.
+        const unsigned long long dv = (unsigned long long)(OP == OP_INCR ? V : 0u - V) << 32;
+        const uint64_t old = atomicAdd(reinterpret_cast<unsigned long long*>(&cells[pos]), dv);
+        if (cell_key(old) == 0) { result = cell_val(old) + (OP == OP_INCR ? V : 0u - V); break; }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull - dv);
+        c = old;
+      }
       if (cell_key(c) == 0) {
         uint32_t nv = OP == OP_INCR ? cell_val(c) + V : OP == OP_DECR ? cell_val(c) - V : V;
         uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]),
@@ -393,14 +408,15 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
 // directory lookup + the per-op body (MODE as in apply_row)
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
-                                     uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false) {
+                                     uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false,
+                                     bool no_ret = false) {
   uint4 s;
   DirSlot* d = dir_find(dir, dmask, X, &s);
   if (!d || s.z == 0) {
     *deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
     return 0;
   }
-  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket);
+  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket, no_ret);
 }
 
 #ifndef SMX_APPLY_SGPRS
@@ -512,7 +528,7 @@ constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/
 #ifndef SMX_AGG_SGPRS
 #define SMX_AGG_SGPRS 80
 #endif
-template <int OP, uint32_t ST = 1>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare)
+template <int OP, uint32_t ST = 1, bool RET = true>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare); RET: results wanted
 __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_apply_agg(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -627,7 +643,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
         LongProbe lp{false, nullptr, 0, 0};
-        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5);
+        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5, !RET);
         if (lp.need) { deferred = true; ctl->n_long = 1; }
         old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
       }
@@ -645,10 +661,10 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       LongProbe lp{false, nullptr, 0, 0};
       uint32_t r = apply_one<OP, false, 1>(dir, dmask, arena, xs[(size_t)j[k] * ST], ys[(size_t)j[k] * ST], V[k], &deferred, &lp);
       if (lp.need) { deferred = true; ctl->n_long = 1; }
-      if (!deferred) out[j[k]] = r;
+      if (!deferred && RET) out[j[k]] = r;
     } else if (slot[k] != ~0u) {
       deferred = reinterpret_cast<uint32_t*>(&l_key[slot[k]])[0] != 0;
-      if (!deferred) {
+      if (!deferred && RET) {                                  // (!RET: the caller does not want the results)
         const uint32_t old = l_sum[slot[k]];
         out[j[k]] = OP == OP_INCR ? old + pre[k] + V[k] : old - pre[k] - V[k];
       }
@@ -1130,6 +1146,10 @@ __global__ __launch_bounds__(256) void k_fix_count(Ctl* ctl, DirSlot* dir, uint3
 // A row is ELIGIBLE if its table can end at no more than 2^FIX_MAX_LG cells even if every pending op is a new key;
 // it gets a block of that bound's size class when the bound exceeds its present size.
 constexpr uint32_t SCAN_TILE = 2048;
+// not for the bulk path: a row whose table could end above 2^FIX_MAX_LG cells, or that the round loop has flagged
+__device__ inline bool fix_row_eligible(const DirSlot& d, uint32_t c) {
+  return fix_bound_lg(d.used, c, meta_lg(d.meta)) <= FIX_MAX_LG && !(d.meta & (META_GROW | META_REBAL));
+}
 __device__ inline uint64_t fix_elem(const DirSlot* dir, const uint32_t* cnt, const uint32_t* touched, uint32_t i, uint32_t nrows,
                                     uint64_t* wide) {
   if (i >= nrows) return 0;
@@ -1137,7 +1157,7 @@ __device__ inline uint64_t fix_elem(const DirSlot* dir, const uint32_t* cnt, con
   const uint32_t c = cnt[h];
   const DirSlot d = dir[h];
   const uint32_t lg = meta_lg(d.meta), lgb = fix_bound_lg(d.used, c, lg);
-  if (lgb > FIX_MAX_LG) return (uint64_t)c;                        // ineligible: ops only (they go back to the list)
+  if (!fix_row_eligible(d, c)) return 0;                           // its ops go straight back to the list (k_fix_scatter)
   if (lgb == FIX_MAX_LG) *wide = 1;                                // the second k_fix_rows pass has work (benign race: all store 1)
   return (uint64_t)c | ((uint64_t)(lgb > lg ? (uint32_t)units_of_lg(lgb) : 0u) << 32);
 }
@@ -1201,11 +1221,18 @@ __global__ __launch_bounds__(256) void k_fix_scan_add(const Ctl* ctl, uint64_t* 
 }
 
 // pass 3: the op indices, row by row -- the same LDS fold: a workgroup reserves its share of a row's range once
-__global__ __launch_bounds__(256) void k_fix_scatter(uint32_t n, const uint32_t* defer, const uint32_t* where,
-                                                     const uint64_t* excl, const uint32_t* pos_of, uint32_t* cursor, uint32_t* grouped) {
+__global__ __launch_bounds__(256) void k_fix_scatter(Ctl* ctl, const DirSlot* dir, const uint32_t* cnt, uint32_t n, const uint32_t* defer,
+                                                     const uint32_t* where, const uint64_t* excl, const uint32_t* pos_of, uint32_t* cursor,
+                                                     uint32_t* grouped, uint32_t* defer_out) {
+  // ops of eligible rows go to their row's range of `grouped`; ops of the others -- a hot row's millions among them -- go
+  // straight back to the round loop's list, one reservation per workgroup (copying them back row by row, one wave per
+  // row, took 27 ms for the 4 M ops of one hot item)
+  constexpr uint32_t BACK = 0x80000000u;
   __shared__ uint32_t l_key[FIXC_SLOTS], l_cnt[FIXC_SLOTS];
+  __shared__ uint32_t l_nback, l_bbase;
   for (uint32_t t0 = blockIdx.x * 256u * FIXC_OPT; t0 < n; t0 += gridDim.x * 256u * FIXC_OPT) {   // block-uniform
     for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) { l_key[i] = FIX_NONE; l_cnt[i] = 0; }
+    if (threadIdx.x == 0) l_nback = 0;
     __syncthreads();
     uint32_t hb[FIXC_OPT], qb[FIXC_OPT], rk[FIXC_OPT];
 #pragma unroll
@@ -1224,12 +1251,20 @@ __global__ __launch_bounds__(256) void k_fix_scatter(uint32_t n, const uint32_t*
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256)
-      if (l_cnt[i]) l_cnt[i] = (uint32_t)excl[pos_of[l_key[i]]] + atomicAdd(&cursor[l_key[i]], l_cnt[i]);   // -> this workgroup's first position
+      if (l_cnt[i]) {
+        const uint32_t h = l_key[i];
+        if (fix_row_eligible(dir[h], cnt[h])) l_cnt[i] = (uint32_t)excl[pos_of[h]] + atomicAdd(&cursor[h], l_cnt[i]);   // -> this workgroup's first position
+        else l_cnt[i] = BACK | atomicAdd(&l_nback, l_cnt[i]);                                                            // (a workgroup holds < 2^31 ops)
+      }
+    __syncthreads();
+    if (threadIdx.x == 0 && l_nback) l_bbase = atomicAdd(&ctl->n_defer, l_nback);
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < FIXC_OPT; k++) {
       if (hb[k] == FIX_NONE) continue;
-      grouped[l_cnt[qb[k]] + rk[k]] = defer[t0 + k * 256u + threadIdx.x];
+      const uint32_t at = l_cnt[qb[k]], j = defer[t0 + k * 256u + threadIdx.x];
+      if (at & BACK) defer_out[l_bbase + (at & ~BACK) + rk[k]] = j;
+      else grouped[at + rk[k]] = j;
     }
     __syncthreads();
   }
@@ -1250,7 +1285,7 @@ __device__ inline uint32_t fix_probe(const uint64_t* T, uint32_t mask, uint32_t 
 // exactly as smatrix_rmap_resize does it -- and the rest goes on.  (A first version ran the reference's code with one
 // lane per row: 6.0 ms per 15 M-op batch; one op at a time with wave-wide probing: 3.4 ms.)
 // Two instantiations share the rows: MAXLG = FIX_MAX_LG - 1 takes every row that can end at <= 256 cells (5 KB of LDS
-// per wave: 28 waves per CU) and hands the ineligible ones back; MAXLG = FIX_MAX_LG takes the rows that may reach 512.
+// per wave: 28 waves per CU) and clears the counts of the ineligible ones (k_fix_scatter sent their ops back); MAXLG = FIX_MAX_LG takes the rows that may reach 512.
 template <int OP, uint32_t MAXLG>
 __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
     Ctl* ctl, DirSlot* dir, const uint32_t* touched, uint8_t* arena, uint32_t* cnt, uint32_t* cursor, const uint64_t* excl,
@@ -1300,17 +1335,13 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
       const uint32_t p0 = (uint32_t)e;
       const uint32_t lg0 = meta_lg(d.meta);
       const uint32_t lgb = fix_bound_lg(d.used, c, lg0);
-      if (MAXLG == FIX_MAX_LG ? lgb != FIX_MAX_LG : lgb == FIX_MAX_LG) continue;         // the other pass's row
-      if (lgb > FIX_MAX_LG || (d.meta & (META_GROW | META_REBAL))) {
-        // not for this path: the row's ops go back to the round loop
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&ctl->n_defer, c);
-        at = (uint32_t)__shfl((int)at, 0);
-        for (uint32_t i = lane; i < c; i += 64) defer_out[at + i] = grouped[p0 + i];
-        wsync();
-        if (lane == 0) { cnt[h] = 0; cursor[h] = 0; }
+      if (!fix_row_eligible(d, c)) {
+        // not for this path: k_fix_scatter has sent the row's ops back to the round loop already (the first pass,
+        // which always runs, clears the row's count)
+        if (MAXLG == FIX_MAX_LG - 1 && lane == 0) { cnt[h] = 0; cursor[h] = 0; }
         continue;
       }
+      if (MAXLG == FIX_MAX_LG ? lgb != FIX_MAX_LG : lgb == FIX_MAX_LG) continue;         // the other pass's row
       wsync();
       if (lane == 0) { cnt[h] = 0; cursor[h] = 0; }                 // taken; and both arrays are all-zero again for the next batch
       uint32_t cur = 0;                                             // which of the two LDS tables is live

@@ -328,6 +328,7 @@ struct Matrix {
   DevBuf<uint64_t> cellp;
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
   DevBuf<uint64_t> soff;
+  bool no_ret = false;                  // the write batch in flight has no result array (d_out == NULL, CF import)
   DevBuf<uint32_t> big;                 // getrow: rows too large for one wave
   DevBuf<uint32_t> seg;                 // getrow: their segments (first segment per row, then a count per segment)
   uint32_t* d_small = nullptr;          // 16 words of scratch
@@ -455,12 +456,19 @@ void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, con
 template <int OP>
 void launch_apply_agg(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                       const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
-  if (m->in_stride == 3)
-    hipLaunchKernelGGL((k_apply_agg<OP, 3>), dim3(blocks_for(n, AGG_TILE)), dim3(AGG_THREADS), 0, s, m->d_ctl,
-                       m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
-  else
-    hipLaunchKernelGGL((k_apply_agg<OP>), dim3(blocks_for(n, AGG_TILE)), dim3(AGG_THREADS), 0, s, m->d_ctl,
-                       m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  // no result array from the caller: the instantiation that skips the results (and may take the paths that are exact in
+  // the table but not in what they would have returned)
+  const dim3 grid(blocks_for(n, AGG_TILE)), block(AGG_THREADS);
+  if (m->no_ret) {
+    if (m->in_stride == 3)
+      hipLaunchKernelGGL((k_apply_agg<OP, 3, false>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+    else
+      hipLaunchKernelGGL((k_apply_agg<OP, 1, false>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  } else if (m->in_stride == 3) {
+    hipLaunchKernelGGL((k_apply_agg<OP, 3>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  } else {
+    hipLaunchKernelGGL((k_apply_agg<OP>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  }
   HIP_OK(hipGetLastError());
 }
 
@@ -603,8 +611,8 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
                      m->fx_excl.p, m->fx_tiles.p, m->fx_tiles.p + ntiles + 1);
   hipLaunchKernelGGL(k_fix_scan_tops, dim3(1), dim3(1024), 0, s, m->fx_tiles.p, ntiles, m->fx_tiles.p + ntiles);
   hipLaunchKernelGGL(k_fix_scan_add, dim3(blocks_for(std::max<uint32_t>(rows_max, 1))), dim3(256), 0, s, m->d_ctl, m->fx_excl.p, m->fx_tiles.p);
-  hipLaunchKernelGGL(k_fix_scatter, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXC_OPT), 8192)), dim3(256), 0, s, nd, dl, m->fx_where.p, m->fx_excl.p,
-                     m->fx_pos.p, m->fx_cur.p, m->fx_grouped.p);
+  hipLaunchKernelGGL(k_fix_scatter, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXC_OPT), 8192)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->fx_cnt.p, nd, dl, m->fx_where.p, m->fx_excl.p,
+                     m->fx_pos.p, m->fx_cur.p, m->fx_grouped.p, dl_out);
   HIP_OK(hipGetLastError());
   uint64_t tw[2] = {0, 0};
   HIP_OK(hipMemcpyAsync(tw, m->fx_tiles.p + ntiles, 16, hipMemcpyDeviceToHost, s));
@@ -976,8 +984,10 @@ int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
-  if (!d_out && n) { m->so.need(n); d_out = m->so.p; }    // results not wanted: they land in the library's own staging buffer
+  // results not wanted: the kernels that always write them get the library's own staging buffer
+  if (!d_out && n) { m->so.need(n); d_out = m->so.p; m->no_ret = true; }
   apply_dev_locked(self, op, n, d_x, d_y, d_v, d_out, s);
+  m->no_ret = false;
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
 }
@@ -992,8 +1002,9 @@ int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* 
   cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
   m->in_stride = width;
-  if (!d_out && n) { m->so.need(n); d_out = m->so.p; }
+  if (!d_out && n) { m->so.need(n); d_out = m->so.p; m->no_ret = true; }
   apply_dev_locked(self, op, n, d_records, d_records + 1, d_records + 2, d_out, s);
+  m->no_ret = false;
   m->in_stride = 1;
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -1014,7 +1025,9 @@ int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, co
     m->sv.need(n);
     HIP_OK(hipMemcpyAsync(m->sv.p, v, n * 4, hipMemcpyHostToDevice, s));
   }
+  m->no_ret = out == nullptr;
   apply_dev_locked(self, op, n, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);
+  m->no_ret = false;
   if (out) HIP_OK(hipMemcpyAsync(out, m->so.p, n * 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -1427,7 +1440,9 @@ int smatrix_cf_import_sessions_dev(smatrix_t* self, size_t n_sessions, const uin
     hipLaunchKernelGGL(k_cf_expand, dim3(blocks_for(n)), dim3(256), 0, s, t0, n, (uint32_t)n_sessions, d_offsets, d_ids,
                        d_op_offsets, m->sx.p, m->sy.p, m->sv.p);
     HIP_OK(hipGetLastError());
+    m->no_ret = true;
     apply_dev_locked(self, OP_INCR, n, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);
+    m->no_ret = false;
   }
   if (!hip_stream) HIP_OK(hipStreamSynchronize(s));
   return 0;

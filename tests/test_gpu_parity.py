@@ -6,6 +6,8 @@ import hashlib
 import threading
 
 import numpy as np
+import ctypes as _C
+_u32p = _C.POINTER(_C.c_uint32)
 import pytest
 
 from libsmatrix_amd.stream import Stream
@@ -820,16 +822,22 @@ def test_column_zero_totals_under_contention(G):
     n = 1 << 22
     x = rng.choice(np.array([5, 6, 7, 1000003], np.uint32), n, p=[0.7, 0.2, 0.09, 0.01]).astype(np.uint32)
     y = np.where(rng.random(n) < 0.8, 0, rng.integers(1, 50000, n)).astype(np.uint32)
-    g = G()
-    for a in range(0, n, 1 << 20):                       # four batches: the rows grow in between
-        g.apply(2, x[a:a + (1 << 20)], y[a:a + (1 << 20)], np.ones(1 << 20, np.uint32))
-    for item in (5, 6, 7, 1000003):
-        assert g.get(item, 0) == int(((x == item) & (y == 0)).sum()), item
     k = (x.astype(np.uint64) << 32 | y)[y != 0]
     uk, cnt = np.unique(k, return_counts=True)
-    got = g.apply(0, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32))
-    assert (got == cnt).all()
-    g.close()
+    for with_results in (True, False):                   # False: out == NULL -> the 64-bit-add form of the column-0 update
+        g = G()
+        for a in range(0, n, 1 << 20):                   # four batches: the rows grow in between
+            xs_, ys_ = x[a:a + (1 << 20)], y[a:a + (1 << 20)]
+            if with_results:
+                g.apply(2, xs_, ys_, np.ones(1 << 20, np.uint32))
+            else:
+                assert g.m._lib.smatrix_apply_batch(g.m._h, 2, xs_.size, xs_.ctypes.data_as(_u32p), ys_.ctypes.data_as(_u32p),
+                                                    np.ones(1 << 20, np.uint32).ctypes.data_as(_u32p), None) == 0
+        for item in (5, 6, 7, 1000003):
+            assert g.get(item, 0) == int(((x == item) & (y == 0)).sum()), (item, with_results)
+        got = g.apply(0, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32))
+        assert (got == cnt).all()
+        g.close()
 
 
 def test_cf_recommender_write_path_on_device(G, oracle_mod):

@@ -15,7 +15,7 @@ def kernel_source_sha16():
 
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 raw = open(os.path.join(G, "prof_pmc_raw.txt")).read()
-AGG, GET = "smx::k_apply_agg<2, 1u>", "smx::k_apply<0>"
+AGG, GET = "smx::k_apply_agg<2, 1u, true>", "smx::k_apply<0>"
 
 
 def val(kern, grid, ctr):
