@@ -83,13 +83,15 @@ class SparseMatrix:
         return int(self._h.contents.mem)
 
     # ---- batched API --------------------------------------------------------
-    def apply_batch(self, op, x, y, v=None):
+    def apply_batch(self, op, x, y, v=None, results=True):
+        """results=False: no result array is passed (include/smatrix_batch.h: the table ends in the same state, the
+        kernels skip the results) and None is returned"""
         x, y = _u32(x), _u32(y)
         assert x.shape == y.shape
-        out = np.empty_like(x)
+        out = np.empty_like(x) if results else None
         vv = _u32(v) if v is not None else None
         self._lib.smatrix_apply_batch(self._h, op, x.size, _p(x), _p(y),
-                                      _p(vv) if vv is not None else None, _p(out))
+                                      _p(vv) if vv is not None else None, _p(out) if results else None)
         return out
 
     def get_batch(self, x, y):
