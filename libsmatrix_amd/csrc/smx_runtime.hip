@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/smatrix_batch.h"
@@ -63,6 +64,45 @@ inline void zero_async(void* p, size_t bytes, hipStream_t st) {
   for (size_t off = 0; off < bytes; off += (size_t)1 << 30)
     HIP_OK(hipMemsetAsync(static_cast<uint8_t*>(p) + off, 0, std::min<size_t>((size_t)1 << 30, bytes - off), st));
 }
+
+// Physical chunks of closed matrices are kept for the next one of the same process (up to SMATRIX_CHUNK_POOL_GB, default 64;
+// 0 = give everything back at once).  Memory handed back to the driver is wiped before it can be handed out again, and an
+// allocation that lands on memory still waiting for that wipe blocks: a 12.5 GB growth step of a matrix opened right after
+// a 27 GB one had been closed was measured at 3.2 s against the usual 2 ms.  Chunks come in a few fixed sizes so that they fit
+// again; the arena zero-fills whatever it maps, reused or fresh.
+struct ChunkPool {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, hipMemGenericAllocationHandle_t> free_chunks;    // (device, bytes) -> handle
+  size_t bytes = 0, cap = (size_t)64 << 30;
+  bool cap_read = false;
+  bool take(int dev, size_t n, hipMemGenericAllocationHandle_t* h) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = free_chunks.find({dev, n});
+    if (it == free_chunks.end()) return false;
+    *h = it->second;
+    free_chunks.erase(it);
+    bytes -= n;
+    return true;
+  }
+  bool put(int dev, size_t n, hipMemGenericAllocationHandle_t h) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!cap_read) {
+      if (const char* e = getenv("SMATRIX_CHUNK_POOL_GB")) cap = (size_t)strtoull(e, nullptr, 10) << 30;
+      cap_read = true;
+    }
+    if (bytes + n > cap) return false;
+    free_chunks.insert({{dev, n}, h});
+    bytes += n;
+    return true;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& c : free_chunks) (void)hipMemRelease(c.second);
+    free_chunks.clear();
+    bytes = 0;
+  }
+};
+inline ChunkPool& chunk_pool() { static ChunkPool* p = new ChunkPool; return *p; }     // (never destroyed: no HIP calls at exit)
 
 struct Arena {
   uint8_t* base = nullptr;
@@ -124,11 +164,14 @@ struct Arena {
       ad.flags = hipMemAccessFlagsProtReadWrite;
       // physical chunks (and the fills that zero them) of at most 1 GiB each: a growth step of a 10+ GB
       // arena is several GiB, and single > 4 GiB allocations / fills are not something to depend on
-      const size_t kChunk = std::max<size_t>(gran, 1ull << 30) / gran * gran;
+      // (in a few fixed sizes -- 1 GiB, 256, 64, 16, 4 MiB, then single granules -- so that the chunks of a closed matrix fit
+      //  the next one's growth steps: ChunkPool)
       while (total) {
-        const size_t add = std::min(total, kChunk);
+        size_t add = gran;
+        for (size_t sz = (size_t)1 << 30; sz >= ((size_t)4 << 20); sz >>= 2)
+          if (sz % gran == 0 && sz <= total) { add = sz; break; }
         hipMemGenericAllocationHandle_t h;
-        HIP_OK(hipMemCreate(&h, add, &prop, 0));
+        if (!chunk_pool().take(device, add, &h)) HIP_OK(hipMemCreate(&h, add, &prop, 0));
         HIP_OK(hipMemMap(base + mapped, add, 0, h, 0));
         // Access for the new chunk only where the runtime takes a sub-range (the HIP 7.0 runtime bundled
         // with PyTorch does; there the whole-range form costs ~8 ms per mapped GB: 30-60 ms per growth of a
@@ -161,7 +204,7 @@ struct Arena {
       size_t off = 0;
       for (auto& c : chunks) {
         (void)hipMemUnmap(base + off, c.second);
-        (void)hipMemRelease(c.first);
+        if (!chunk_pool().put(device, c.second, c.first)) (void)hipMemRelease(c.first);
         off += c.second;
       }
       if (base) (void)hipMemAddressFree(base, reserved);
@@ -1474,6 +1517,9 @@ int smatrix_cf_import_sessions(smatrix_t* self, size_t n_sessions, const uint64_
   (void)hipFree(d_off); (void)hipFree(d_op); (void)hipFree(d_ids);
   return rc;
 }
+
+// physical chunks kept from closed matrices (ChunkPool) go back to the driver now
+void smatrix_release_cached_memory(void) { chunk_pool().trim(); }
 
 // ---- introspection -------------------------------------------------------------------
 void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
