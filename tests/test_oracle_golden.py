@@ -175,3 +175,23 @@ def test_fileformat(oracle_mod, golden, tmp_path):
         assert getattr(m, op)(*a) == want, (op, a)
     assert m.num_rows() == g["rows_after_reopen"]
     m.close()
+
+
+def test_cf_example_restatement_known_answers():
+    """examples/cf_recommender.c:36-47 + :50-86 as restated in oracle/smatrix_oracle.c, on a case small enough to do by
+    hand: sessions (5,7,9) and (9,9).  Column 0 holds the totals; the pair test is on POSITIONS, so the doubled 9 counts
+    itself; neighbours come in slot order with cc / (sqrt(total_a) * sqrt(total_b)), the (0,total) entry scoring 0."""
+    from oracle import oracle as O
+    o = O.Oracle()
+    O.cf_import_preference_set(o, [5, 7, 9])
+    O.cf_import_preference_set(o, [9, 9])
+    assert [o.get(a, 0) for a in (5, 7, 9)] == [1, 1, 3]
+    assert o.get(5, 7) == o.get(7, 5) == o.get(5, 9) == o.get(9, 5) == o.get(7, 9) == o.get(9, 7) == 1
+    assert o.get(9, 9) == 2 and o.get(5, 5) == 0
+    ids, sc = O.cf_neighbors(o, 9, 100)
+    got = dict(zip(ids.tolist(), sc.tolist()))
+    assert set(got) == {0, 5, 7, 9}
+    assert got[0] == 0.0                                   # num 3 > den sqrt(3)*sqrt(1): the example's guard
+    assert got[5] == 1.0 / (np.sqrt(3.0) * np.sqrt(1.0)) and got[7] == got[5]
+    assert got[9] == 2.0 / (np.sqrt(3.0) * np.sqrt(3.0))
+    o.close()
