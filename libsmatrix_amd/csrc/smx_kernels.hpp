@@ -689,6 +689,99 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
   }
 }
 
+// ---- set batches: the same fold, keeping each key's LAST op --------------------------------------------------
+// A set batch resolves duplicates highest-index-wins (include/smatrix_batch.h).  One atomicExch per op serialises on
+// the hot cells exactly like un-folded incrs did (13 ms per 2^24 Zipf ops), and five passes over ALL ops then put the
+// right values in.  Here a tile first reduces its ops to one WINNER per distinct key (LDS claim + LDS atomicMax on the op
+// index); only winners touch the table -- found or inserted like any write, their value lands for now -- and only
+// winners enter the passes that settle the order ACROSS tiles after the rounds (k_set_*_e below: locate, clear, rank by
+// atomicMax of the op index, pick, store): ~0.7 n entries, at most one per tile on a hot cell.
+// set returns the value it was given (src/smatrix.c:230): out[i] = v[i], written at once.
+// LDS empty marker: key 0 = (x 0, y 0), which never enters the table (y == 0 ops take the per-op body: quirk Q1).
+template <uint32_t ST = 1>
+__global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_set_fold(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, const uint32_t* __restrict__ vs,
+    uint32_t* __restrict__ out, uint32_t* defer, uint32_t* __restrict__ ent_idx) {
+  __shared__ uint64_t l_key[AGG_SLOTS];     // (x | y<<32), 0 = empty
+  __shared__ uint32_t l_win[AGG_SLOTS];     // highest op index + 1 among the tile's ops on the key
+  __shared__ uint16_t l_list[AGG_TILE];
+  __shared__ uint32_t l_n, l_base;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < AGG_SLOTS; i += AGG_THREADS) { l_key[i] = 0ull; l_win[i] = 0; }
+  if (tid == 0) l_n = 0;
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * AGG_TILE;
+  uint32_t own = 0;                         // this lane's ops with y == 0
+#pragma unroll
+  for (uint32_t k = 0; k < AGG_OPT; k++) {
+    const uint32_t t = tile0 + k * AGG_THREADS + tid;
+    if (t >= n) continue;
+    const uint32_t X = xs[(size_t)t * ST], Y = ys[(size_t)t * ST];
+    out[t] = vs[(size_t)t * ST];
+    if (Y == 0) { own |= 1u << k; continue; }
+    const uint64_t key = (uint64_t)X | ((uint64_t)Y << 32);
+    uint32_t h = (X * 0x9E3779B1u) ^ (Y * 0x85EBCA77u);
+    h = (h ^ (h >> 15)) & (AGG_SLOTS - 1);
+    for (;;) {
+      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&l_key[h]), 0ull, (unsigned long long)key);
+      if (prev == 0ull) l_list[atomicAdd(&l_n, 1u)] = (uint16_t)h;
+      if (prev == 0ull || prev == key) break;
+      h = (h + 1) & (AGG_SLOTS - 1);
+    }
+    atomicMax(&l_win[h], t + 1u);
+  }
+  __syncthreads();
+  const uint32_t nd = l_n;
+  uint32_t dm = 0, wj[AGG_OPT];             // winners that could not be applied: they go to the round loop
+#pragma unroll
+  for (uint32_t q = 0; q < AGG_OPT; q++) {
+    const uint32_t i = tid + q * AGG_THREADS;
+    uint32_t e = 0;
+    if (i < nd) {
+      const uint32_t h = l_list[i];
+      const uint64_t key = l_key[h];
+      const uint32_t w = l_win[h] - 1u;
+      bool deferred = false;
+      LongProbe lp{false, nullptr, 0, 0};
+      apply_one<OP_SET, true, 1>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), vs[(size_t)w * ST], &deferred, &lp);
+      if (lp.need) { deferred = true; ctl->n_long = 1; }
+      if (deferred) { dm |= 1u << q; wj[q] = w; }
+      e = w + 1u;
+    }
+    ent_idx[tile0 + i] = e;                 // (the entry arrays hold gridDim.x * AGG_TILE slots)
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < AGG_OPT; k++) {
+    if (!(own & (1u << k))) continue;
+    const uint32_t t = tile0 + k * AGG_THREADS + tid;
+    bool deferred = false;
+    LongProbe lp{false, nullptr, 0, 0};
+    apply_one<OP_SET, false, 1>(dir, dmask, arena, xs[(size_t)t * ST], 0u, vs[(size_t)t * ST], &deferred, &lp);
+    if (lp.need) { deferred = true; ctl->n_long = 1; }
+    if (deferred) { dm |= 1u << (AGG_OPT + k); }
+  }
+  // deferred ops: one reservation per workgroup
+  __syncthreads();
+  if (tid == 0) l_n = 0;
+  __syncthreads();
+  const uint32_t mine = __popc(dm);
+  uint32_t at = 0;
+  if (mine) at = atomicAdd(&l_n, mine);
+  __syncthreads();
+  if (tid == 0 && l_n) l_base = atomicAdd(&ctl->n_defer, l_n);
+  __syncthreads();
+  if (mine) {
+    at += l_base;
+#pragma unroll
+    for (uint32_t q = 0; q < AGG_OPT; q++)
+      if (dm & (1u << q)) defer[at++] = wj[q];
+#pragma unroll
+    for (uint32_t k = 0; k < AGG_OPT; k++)
+      if (dm & (1u << (AGG_OPT + k))) defer[at++] = tile0 + k * AGG_THREADS + tid;
+  }
+}
+
 // ---- prep kernel --------------------------------------------------------------
 //
 // Runs over the ops the op kernel deferred, on a quiescent table:
@@ -1923,6 +2016,58 @@ __global__ __launch_bounds__(256) void k_set_store(uint32_t n, const uint64_t* c
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n && cellp[j] != ~0ull)
     reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = vs[(size_t)j * st];
+}
+
+// the same five passes over the ENTRIES of k_set_fold (ent_idx[e] = winner's op index + 1, 0 = no entry)
+__global__ __launch_bounds__(256) void k_set_locate_e(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_ent,
+                                                      const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+                                                      uint32_t* ent_idx, uint64_t* ent_cell, uint32_t st) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t w1 = e < n_ent ? ent_idx[e] : 0u;
+  const bool live = w1 != 0;
+  const uint32_t j = w1 - 1u;
+  uint64_t where = ~0ull;
+  const uint32_t Y = live ? ys[(size_t)j * st] : 0u;
+  uint4 s = {0, 0, 0, 0};
+  DirSlot* d = live ? dir_find(dir, dmask, xs[(size_t)j * st], &s) : nullptr;
+  LongProbe lp{false, nullptr, 0, 0};
+  if (d && s.z) {
+    const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
+    const uint64_t* cells = row_cells(arena, s.z);
+    uint32_t pos = Y & mask;
+    for (uint32_t step = 0; step <= mask; step++) {
+      const uint64_t c = cells[pos];
+      if (cell_key(c) == Y) { where = (((uint64_t)s.z) << 4) + pos; break; }
+      if (c == 0) break;
+      pos = (pos + 1) & mask;
+      if (step >= PROBE_BUDGET) { lp = LongProbe{true, cells, mask, pos}; break; }
+    }
+  }
+  while (__any(lp.need)) {
+    const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+    if (lp.need) {
+      lp.need = false;
+      if (p != PROBE_NONE && cell_key(lp.cells[p]) == Y) where = (((uint64_t)s.z) << 4) + p;
+    }
+  }
+  if (live) {
+    ent_cell[e] = where;
+    if (where == ~0ull) ent_idx[e] = 0;
+    else reinterpret_cast<uint32_t*>(arena)[where * 2 + 1] = 0;          // (k_set_clear's job, done here)
+  }
+}
+__global__ __launch_bounds__(256) void k_set_rank_e(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_ent && ent_idx[e]) atomicMax(&reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1], ent_idx[e]);
+}
+__global__ __launch_bounds__(256) void k_set_pick_e(uint32_t n_ent, uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_ent && ent_idx[e] && reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] != ent_idx[e]) ent_idx[e] = 0;   // loser
+}
+__global__ __launch_bounds__(256) void k_set_store_e(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell,
+                                                     const uint32_t* __restrict__ vs, uint8_t* arena, uint32_t st) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_ent && ent_idx[e]) reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = vs[(size_t)(ent_idx[e] - 1u) * st];
 }
 
 // ---- directory growth -----------------------------------------------------------

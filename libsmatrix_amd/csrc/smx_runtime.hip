@@ -372,6 +372,8 @@ struct Matrix {
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
   DevBuf<uint64_t> soff;
   bool no_ret = false;                  // the write batch in flight has no result array (d_out == NULL, CF import)
+  uint32_t set_entries = 0;             // set batch in flight: entries of k_set_fold (0: the batch went op by op)
+  DevBuf<uint32_t> ent_idx;
   DevBuf<uint32_t> big;                 // getrow: rows too large for one wave
   DevBuf<uint32_t> seg;                 // getrow: their segments (first segment per row, then a count per segment)
   uint32_t* d_small = nullptr;          // 16 words of scratch
@@ -522,7 +524,22 @@ void launch_apply_op(Matrix* m, int op, hipStream_t s, uint32_t n, const uint32_
   if (timed) HIP_OK(hipEventRecord(m->ev0, s));
   switch (op) {
     case OP_GET:  launch_apply<OP_GET>(m, s, n, idx, x, y, v, out, defer); break;
-    case OP_SET:  launch_apply<OP_SET>(m, s, n, idx, x, y, v, out, defer); break;
+    case OP_SET:
+      if (idx == nullptr && !m->long_probes && n >= m->agg_min) {
+        // round 0 of a set batch: one winner per distinct key and tile (k_set_fold); the passes after the rounds run over
+        // these entries
+        const uint32_t tiles = blocks_for(n, AGG_TILE);
+        m->set_entries = tiles * AGG_TILE;
+        m->ent_idx.need(m->set_entries);
+        if (m->in_stride == 3)
+          hipLaunchKernelGGL((k_set_fold<3>), dim3(tiles), dim3(AGG_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, v, out, defer, m->ent_idx.p);
+        else
+          hipLaunchKernelGGL((k_set_fold<1>), dim3(tiles), dim3(AGG_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, v, out, defer, m->ent_idx.p);
+        HIP_OK(hipGetLastError());
+      } else {
+        launch_apply<OP_SET>(m, s, n, idx, x, y, v, out, defer);
+      }
+      break;
     case OP_INCR:
       if (!m->long_probes && n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
       else launch_apply<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
@@ -691,7 +708,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   m->dirty = true;
   m->defer[0].need(n);
   m->defer[1].need(n);
-  if (op == OP_SET) m->cellp.need(n);
+  if (op == OP_SET) m->cellp.need((size_t)n + AGG_TILE);
+  m->set_entries = 0;
   m->st.batches++;
   if (m->dbg_after && m->st.batches == m->dbg_after) {     // measurement builds (SMX_AGG_DBG): switch the kernel's debug mode on
     const uint32_t one = 1;
@@ -795,7 +813,17 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     cur_n = nd;
   }
 
-  if (op == OP_SET) {
+  if (op == OP_SET && m->set_entries) {
+    // highest-index-wins across tiles, over the winners of k_set_fold only (locate also clears the value word)
+    const uint32_t ne = m->set_entries;
+    dim3 g(blocks_for(ne)), b(256);
+    hipLaunchKernelGGL(k_set_locate_e, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, ne, x, y, m->ent_idx.p, m->cellp.p, m->in_stride);
+    hipLaunchKernelGGL(k_set_rank_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
+    hipLaunchKernelGGL(k_set_pick_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
+    hipLaunchKernelGGL(k_set_store_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, v, m->arena.base, m->in_stride);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(s));
+  } else if (op == OP_SET) {
     dim3 g(blocks_for(n)), b(256);
     hipLaunchKernelGGL(k_set_locate, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y,
                        m->cellp.p, m->in_stride);
@@ -999,7 +1027,7 @@ void smatrix_close(smatrix_t* self) {
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
-      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release();
+      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
       if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);

@@ -267,6 +267,23 @@ def test_set_batch_duplicates_highest_index_wins(G):
     got = m.apply(0, (ks >> 32).astype(np.uint32), (ks & 0xFFFFFFFF).astype(np.uint32))
     assert got.tolist() == list(last.values())
     m.close()
+    # at scale: 2^22 Zipf ops into an EMPTY matrix (rows created and grown inside the batch, the bulk path, winners that
+    # wait for a round), the all-ones key (no LDS marker may collide with it), then a second batch on the grown table
+    gen = Stream("zipf", 99, 200000, 1.1, 1)
+    m = G()
+    for rep in range(2):
+        x, y = gen.fill(rep << 22, 1 << 22)
+        x = x.copy(); y = y.copy()
+        x[::100003] = 0xFFFFFFFF; y[::100003] = 0xFFFFFFFF
+        v = rng.integers(0, 1 << 32, x.size, dtype=np.uint64).astype(np.uint32)
+        assert (m.apply(1, x, y, v) == v).all()
+        k = x.astype(np.uint64) << 32 | y
+        uk, first_rev = np.unique(k[::-1], return_index=True)             # first in the reversed batch = last in the batch
+        want = v[::-1][first_rev]
+        got = m.apply(0, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32))
+        assert (got == want).all(), rep
+        assert int(m.m.rowlen_batch(np.unique(x)).astype(np.uint64).sum()) >= uk.size
+    m.close(); gen.close()
 
 
 def test_full_size_batch_properties(G):
