@@ -298,7 +298,8 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
 //           at the slot it found)
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
-                                     bool* deferred, LongProbe* lp, bool dbg_noticket = false, bool no_ret = false) {
+                                     bool* deferred, LongProbe* lp, bool dbg_noticket = false, bool no_ret = false,
+                                     bool exists_only = false) {
   uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
@@ -363,7 +364,8 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
     uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
     if (OP == OP_INCR) result = atomicAdd(vp, V) + V;      // :241, wraps mod 2^32
     else if (OP == OP_DECR) result = atomicSub(vp, V) - V; // :252
-    else { result = V; atomicExch(vp, V); }                // :230 (duplicates: see k_set_locate)
+    else { result = V; if (!exists_only) atomicExch(vp, V); }   // :230 (duplicates: see k_set_locate; exists_only: k_set_fold's
+                                                                //       winners -- the passes after the rounds write the value)
   } else {
     // y == 0 (quirk Q1, src/smatrix.c:297-303,:370-374): the first slot whose KEY
     // field is 0 -- the row's own (0,v) entry or the first empty slot -- is a hit;
@@ -409,14 +411,15 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
                                      uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false,
-                                     bool no_ret = false) {
+                                     bool no_ret = false, bool exists_only = false) {
   uint4 s;
   DirSlot* d = dir_find(dir, dmask, X, &s);
   if (!d || s.z == 0) {
     *deferred = (OP != OP_GET);     // get on an absent row: 0, creates nothing (S1)
     return 0;
   }
-  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket, no_ret);
+  return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket, no_ret,
+                                      exists_only);
 }
 
 #ifndef SMX_APPLY_SGPRS
@@ -744,7 +747,8 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       const uint32_t w = l_win[h] - 1u;
       bool deferred = false;
       LongProbe lp{false, nullptr, 0, 0};
-      apply_one<OP_SET, true, 1>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), vs[(size_t)w * ST], &deferred, &lp);
+      apply_one<OP_SET, true, 1>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), vs[(size_t)w * ST], &deferred, &lp,
+                                 false, false, true);
       if (lp.need) { deferred = true; ctl->n_long = 1; }
       if (deferred) { dm |= 1u << q; wj[q] = w; }
       e = w + 1u;
