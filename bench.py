@@ -563,6 +563,34 @@ def guarded(fn, *a):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def op_kinds_leg(torch, dev, m, x, y, B, stream):
+    """all four op kinds of the path on the finished config-2 table, one 2^24-op batch of present keys each (wall clock
+    around the call, best of 3): get / incr / decr / set, write kinds also without a result array"""
+    from libsmatrix_amd import OP_GET, OP_SET, OP_INCR, OP_DECR
+    ones = torch.ones(B, dtype=torch.int32, device=dev); out = torch.empty_like(ones)
+
+    def timed(op, v, o):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m.apply_batch_dev(op, B, x.data_ptr(), y.data_ptr(), v, o, stream)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best * 1e3
+    r = {}
+    for name, op in (("get", OP_GET), ("incr", OP_INCR), ("decr", OP_DECR)):
+        r[name + "_ms"] = timed(op, ones.data_ptr(), out.data_ptr())
+        if op != OP_GET:
+            r[name + "_no_results_ms"] = timed(op, ones.data_ptr(), None)
+    # set LAST, with the values the cells hold now (a get of the same keys): the table is left as it was
+    m.apply_batch_dev(OP_GET, B, x.data_ptr(), y.data_ptr(), None, out.data_ptr(), stream)
+    vals = out.clone(); o2 = torch.empty_like(out)
+    r["set_ms"] = timed(OP_SET, vals.data_ptr(), o2.data_ptr())
+    r["Gops_per_s"] = {k[:-3]: B / v / 1e6 for k, v in r.items() if k.endswith("_ms")}
+    r["note"] = "present keys (no inserts); set resolves duplicates highest-index-wins (k_set_fold + the entry passes)"
+    return r
+
+
 def sustained_leg(torch, dev, m, gen, first_step, B, seconds, stream):
     from libsmatrix_amd import OP_GET, OP_INCR
     group = 32                                                # batches generated per untimed refill (4 GB of ids)
@@ -854,6 +882,8 @@ def main():
         # (3) dense ids (id = Zipf rank, no scramble): the reference's identity-hash tables cluster here
         #     (displacement 10^3-10^4); secondary metric
         extras["dense_ids"] = guarded(dense_ids_leg, torch, dev, B, stream)
+        # (4) the four op kinds on the finished table
+        extras["op_kinds"] = guarded(op_kinds_leg, torch, dev, m, xs[total_steps - 1], ys[total_steps - 1], B, stream)
 
     total_ops = 2 * B * args.steps * world
     res = {
