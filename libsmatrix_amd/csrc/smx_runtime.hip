@@ -753,7 +753,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       if (timed0) { account_kernel_time(m, op, n); timed0 = false; }
       const uint32_t nd0 = m->h_ctl->n_defer;
       m->expect_bulk = (uint64_t)nd0 * 8 >= n;
-      if (nd0 >= m->fix_min) {
+      if (nd0 >= m->fix_min && nd0 < 0x80000000u) {           // (k_fix_scatter keeps a flag in bit 31 of a position)
         m->st.rounds++;
         m->st.deferred_ops += nd0;
         m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
