@@ -105,6 +105,11 @@ int smatrix_cf_import_sessions(smatrix_t* self, size_t n_sessions, const uint64_
 int smatrix_cf_import_sessions_dev(smatrix_t* self, size_t n_sessions, const uint64_t* d_offsets, const uint32_t* d_ids,
                                    const uint64_t* d_op_offsets, uint64_t total_ops, void* hip_stream);
 
+/* Capacity hint, like vector::reserve: map at least `bytes` of device memory for row tables now instead of in growth
+ * steps later (each step is a call into the driver, normally ~0.3 ms, but one that can block for seconds while the driver
+ * still has freed memory to wipe).  Nothing observable changes.  Returns 0. */
+int smatrix_reserve(smatrix_t* self, uint64_t bytes);
+
 /* smatrix_close keeps up to SMATRIX_CHUNK_POOL_GB (default 64, 0 = nothing) of the closed matrix's device memory for the
  * next matrix this process opens (memory handed back to the driver is wiped before reuse, and allocating into that wipe
  * blocks for seconds); this gives it back at once. */

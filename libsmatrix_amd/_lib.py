@@ -67,6 +67,7 @@ def load():
         "smatrix_cf_neighbors_batch": (C.c_int, [H, C.c_size_t, u32p, u64p, u32p, C.POINTER(C.c_double), u32p]),
         "smatrix_cf_neighbors_batch_dev": (C.c_int, [H, C.c_size_t, V, V, V, V, V, V]),
         "smatrix_release_cached_memory": (None, []),
+        "smatrix_reserve": (C.c_int, [H, C.c_uint64]),
         "smatrix_cf_topk_batch": (C.c_int, [H, C.c_size_t, u32p, C.c_uint32, u32p, C.POINTER(C.c_double), u32p]),
         "smatrix_cf_topk_batch_dev": (C.c_int, [H, C.c_size_t, V, C.c_uint32, V, V, V, V]),
         "smatrix_cf_import_sessions": (C.c_int, [H, C.c_size_t, u64p, u32p]),

@@ -1546,6 +1546,19 @@ int smatrix_cf_import_sessions(smatrix_t* self, size_t n_sessions, const uint64_
   return rc;
 }
 
+// Capacity hint (like vector::reserve): map at least `bytes` of row arena now, so that growth steps -- calls into the
+// driver, which can block for seconds when it still has freed memory to wipe (ChunkPool) -- do not fall into a
+// latency-sensitive phase later.  Changes nothing observable; 0 on success.
+int smatrix_reserve(smatrix_t* self, uint64_t bytes) {
+  Matrix* m = M(self);
+  set_device(m);
+  std::lock_guard<std::mutex> g(m->mu);
+  if (m->arena.vmm && bytes > m->arena.reserved) bytes = m->arena.reserved;
+  if (bytes > m->arena.mapped) m->arena.grow_to(bytes, m->arena_next * UNIT_BYTES, m->stream);
+  HIP_OK(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
 // physical chunks kept from closed matrices (ChunkPool) go back to the driver now
 void smatrix_release_cached_memory(void) { chunk_pool().trim(); }
 

@@ -197,6 +197,10 @@ class SparseMatrix:
             out["kernel_ops_" + op] = st.kernel_ops[i]
         return out
 
+    def reserve(self, nbytes):
+        """capacity hint: map at least nbytes of device memory for row tables now (include/smatrix_batch.h smatrix_reserve)"""
+        self._lib.smatrix_reserve(self._h, int(nbytes))
+
     def flush(self):
         """file mode: dirty rows reach the backing file now (include/smatrix_batch.h smatrix_flush)"""
         self._lib.smatrix_flush(self._h)
