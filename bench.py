@@ -671,6 +671,7 @@ def main():
     ap.add_argument("--rows", type=int, default=None, help="--config 3/5: rows of the CF matrix (default 13M)")
     ap.add_argument("--no-extras", action="store_true",
                     help="config 2 only: skip the legs that are not `value` (reference-checksum replay, sustained run, dense ids, configs 3/5)")
+    ap.add_argument("--no-reserve", action="store_true", help="do not map the row arena up front (A/B of smatrix_reserve)")
     ap.add_argument("--sustain-s", type=float, default=1.5, help="seconds of the sustained (continuing-stream) leg")
     args = ap.parse_args()
 
@@ -753,7 +754,10 @@ def main():
     # has a previous process's freed memory to wipe -- falls into the timed region.  The tables themselves still grow
     # row by row inside it.
     ARENA_RESERVE = 8 << 30
-    (m.local if sharded else m).reserve(ARENA_RESERVE)
+    if args.no_reserve:
+        ARENA_RESERVE = 0
+    else:
+        (m.local if sharded else m).reserve(ARENA_RESERVE)
 
     pending = {}       # sharded: batches whose incr records are already travelling (routed ahead)
 
