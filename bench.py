@@ -9,7 +9,11 @@ src/smatrix_benchmark.c:226-230) = 2 * 2^24 ops.  Batches are generated on the G
 before the timed region, so inputs are resident in HBM when timing starts.
 warmup + steps = 24 batches cover the whole 4e8-op stream (100.4M nnz in 1M rows).
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank draws its
+N>1 = BASELINE.json's config 4: the row-hash-sharded Zipf(1.1) stream over 8M x 8M scrambled ids
+(SURVEY.md 8d), seed 12345 + rank, generated on the device.  `python bench.py --gpus N` launches
+its own N ranks (child processes, spawned before this process touches any GPU) when it was not
+started by torch.distributed.run; `--steps 75` at N=8 is the full 10^10-incr-op stream.
+One process per GPU (torch.distributed, backend nccl = RCCL); every rank draws its
 own slice of the stream, ops are routed to the row's owner shard with all_to_all
 (libsmatrix_amd/sharded.py) and results routed back; the exchange of get(s) overlaps the
 incr kernels of step s and the exchange of incr(s+1) overlaps get(s) (split-phase API on a
@@ -28,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 BATCH_LG = 24
 N_IDS = 1000000
+N_IDS_CONFIG4 = 8000000   # config 4 (N > 1): 8M x 8M ids, SURVEY.md 8(d)
+RING_MAX = 96             # pre-generated batches kept in HBM (12 GB of ids at 2^24 ops per batch)
 ZIPF_S = 1.1
 SEED = 12345
 # algorithmic bytes per op, SURVEY.md 8(d): get = 8 in + 12 cell + 4 out; incr (with return) = 12 + 12 + 4 + 4
@@ -645,6 +651,37 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
 
 
 
+def self_launch(n):
+    """N ranks of this very command line as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, rendezvous on 127.0.0.1); rank 0 inherits stdout (its ONE JSON line), the others' stdout goes to
+    stderr.  Returns the worst exit code; if a rank dies the others are killed by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:
+                    procs[q].kill()                        # (exact PIDs of our own children)
+        time.sleep(0.05)
+    return worst if worst >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -675,6 +712,12 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=1.5, help="seconds of the sustained (continuing-stream) leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as given: this process becomes a launcher.  It spawns N CHILD interpreters, one
+        # rank each, BEFORE anything here has touched a GPU (torch is not even imported yet) and only relays rank 0's
+        # JSON line and the exit codes -- it never execs, and never initialises HIP itself.
+        sys.exit(self_launch(args.gpus))
+
     # ONE JSON line on stdout: everything else that libraries print there (RCCL's version banner at communicator
     # creation, for one) is sent to stderr for the whole run
     json_out = os.fdopen(os.dup(1), "w")
@@ -685,8 +728,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with python -m torch.distributed.run --nproc-per-node %d" % args.gpus)
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.single_device:
         local = 0
         os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"
@@ -718,11 +760,13 @@ def main():
     from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
     B = 1 << args.batch_lg
     total_steps = args.warmup + args.steps
-    gen = Stream("zipf", SEED + (rank if world > 1 else 0), N_IDS, ZIPF_S, 1)
+    # N > 1 is config 4: 8M x 8M ids, every rank its own stream (seed 12345 + rank), generated on the device
+    n_ids = N_IDS_CONFIG4 if world > 1 else N_IDS
+    gen = Stream("zipf", SEED + (rank if world > 1 else 0), n_ids, ZIPF_S, 1)
 
     # inputs live in HBM before the timed region; beyond 32 batches (4 GB) the pre-generated batches are
     # reused cyclically (the stream then repeats: later passes over a batch are all hits)
-    ring = min(total_steps, 32)
+    ring = min(total_steps, RING_MAX if world > 1 else 32)
     xs_all = torch.empty((ring, B), dtype=torch.int32, device=dev)
     ys_all = torch.empty((ring, B), dtype=torch.int32, device=dev)
 
@@ -901,10 +945,17 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "config-2: Zipf(1.1) x Zipf(1.1) over 1M x 1M scrambled ids, seed 12345, "
-                               "batches of 2^%d ops, step = incr batch + get batch on the same keys; "
-                               "table grows from %d to %d batches of the 4e8-op stream during the timed steps"
-                               % (args.batch_lg, args.warmup, total_steps),
+        "config": {"workload": ("config-2: Zipf(1.1) x Zipf(1.1) over 1M x 1M scrambled ids, seed 12345, "
+                                "batches of 2^%d ops, step = incr batch + get batch on the same keys; "
+                                "table grows from %d to %d batches of the 4e8-op stream during the timed steps"
+                                % (args.batch_lg, args.warmup, total_steps)) if world == 1 else
+                               ("config-4: row-hash-sharded Zipf(1.1) x Zipf(1.1) stream over 8M x 8M scrambled ids, one stream per "
+                                "rank (seed 12345 + rank) generated on the device, owner = planned hash ranges of the row id, "
+                                "RCCL exchange over xGMI; step = every rank routes and applies an incr batch of 2^%d ops and a get "
+                                "batch on the same keys; %d ranks x %d steps = %.3g incr ops (+ as many gets) in the timed "
+                                "region (the full 10^10-op stream is --steps 75 at 8 ranks)"
+                                % (args.batch_lg, world, args.steps, float(world) * args.steps * B)),
+                   "ids_per_axis": n_ids,
                    "batch_ops": B, "arena_reserved_bytes": ARENA_RESERVE, "distinct_batches": ring, "parallelism": "row-hash shards x%d" % world if sharded else "single GPU"},
         "sanity_all_gets_positive": ok,
     }
@@ -960,6 +1011,11 @@ def main():
                 "get_frac_of_chain2": g_get / ra["chain2_gtouch_per_s"],
                 "get_frac_of_read8": g_get / ra["read8_gtouch_per_s"],
                 "incr_frac_of_atomic_ret": g_inc / ra["atomic_ret_gtouch_per_s"],
+                # the composite ceiling of the MIXED step: one random read per get, one returning atomic per incr --
+                # 2 ops in 1/read8 + 1/atomic_ret seconds -- next to the north star's plain read8 fraction
+                "mixed_ceiling_gops_per_s": 2.0 / (1.0 / ra["read8_gtouch_per_s"] + 1.0 / ra["atomic_ret_gtouch_per_s"]),
+                "mixed_frac_of_read8": res["value"] / 1e3 / ra["read8_gtouch_per_s"],
+                "mixed_frac_of_mixed_ceiling": res["value"] / 1e3 * (1.0 / ra["read8_gtouch_per_s"] + 1.0 / ra["atomic_ret_gtouch_per_s"]) / 2.0,
                 "note": "ceilings are uniform-random over the buffer; the Zipf stream re-touches hot lines "
                         "in L2/Infinity Cache, so fractions above 1 are cache assistance, not an error",
             })

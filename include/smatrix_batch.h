@@ -138,6 +138,9 @@ typedef struct {
   uint64_t file_rows_written;    /* rows those write-outs wrote (a clean row is never rewritten) */
   uint64_t file_leaked_bytes;    /* row blocks that grown rows left behind in the file since it was opened */
   uint64_t file_compactions;     /* smatrix_compact runs */
+  uint64_t spec_chains;          /* write batches whose rounds 0 and 1 were enqueued at once, with one read-back (run_write) */
+  uint64_t spec_refused;         /* of those: chains in which a growth task did not fit the estimates and was left to the host-driven loop */
+  uint64_t file_bg_flushes;      /* of file_flushes: those the background flusher made (SMATRIX_FLUSH_MS, default 100; 0 = off) */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];
@@ -150,7 +153,10 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
  * place when the row's table still has its on-disk size, else as a fresh block whose CMAP entry is re-pointed, the
  * reference's own scheme, src/smatrix.c:418-496); row blocks first, then the entries that publish them.  smatrix_close
  * does the same one last time.  The reference has no such call: its IO thread flushes continuously (:929-960) and
- * close is its only barrier (:113-133).  SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch, SMATRIX_FSYNC=1
+ * close is its only barrier (:113-133).  Like the reference's IO thread (100 ms poll, :945) a background flusher of this
+ * library writes dirty rows every SMATRIX_FLUSH_MS milliseconds (default 100, 0 = off; it holds the matrix lock while it
+ * writes and therefore pauses for ten times as long as its last flush took), so a process that dies without close
+ * loses about that much.  SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch, SMATRIX_FSYNC=1
  * adds fsync() after the row blocks and after the entries.  Memory mode: no-op.  Returns 0. */
 int smatrix_flush(smatrix_t* self);
 /* File mode: rewrites the backing file without the blocks that grown rows have left behind (like the reference's, the

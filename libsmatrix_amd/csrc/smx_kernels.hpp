@@ -110,6 +110,14 @@ struct Ctl {
   uint32_t pad1;
   uint64_t arena_next;   // bump pointer, units
   int32_t  free_cnt[N_CLASSES];   // retired row blocks ready for reuse, per size class (stack heights)
+  // ---- the device-driven round (k_round_advance; smx_runtime.hip "speculative chain") ----
+  uint32_t n_prev;       // ops the previous op round deferred = the length of the list the next op round reads
+  uint32_t spec_nd0;     // round 0 of the chain, kept for the host's statistics: deferred ops,
+  uint32_t spec_nt0;     //   growth tasks,
+  uint32_t spec_failed;  //   growth tasks refused (budget of tasks / arena units): their rows stay as they are, their ops stay deferred
+  uint64_t spec_gu0;     //   units the growths took
+  uint32_t spec_nrebal0, spec_dirfull0;
+  uint32_t spec_nkind0[4];
 };
 constexpr size_t CTL_ROUND_BYTES = 64;    // one aligned fill
 static_assert(offsetof(Ctl, dir_used) == CTL_ROUND_BYTES, "the per-round part of Ctl is what ctl_reset_round zeroes");
@@ -432,6 +440,8 @@ __device__ __forceinline__ void apply_body(
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
   // st: distance between consecutive ops in xs/ys/vs, in words (1 = three arrays, 2 / 3 = one array of
   // {x,y} / {x,y,v} records with xs = rec, ys = rec + 1, vs = rec + 2: what the sharded exchange delivers)
+  // n == 0xFFFFFFFF: the list's length is on the device (ctl->n_prev: the host has not read the previous round back)
+  if (n == 0xFFFFFFFFu) n = aload(&ctl->n_prev);
   for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
@@ -1597,17 +1607,55 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
 // allocate the new block of every task -- from the stack of retired blocks of its size class where
 // one is left (popped with one atomic per class and workgroup), else from the arena -- and assign
 // the chunk ranges of the move/finish passes
-__device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl) {
+// task_budget / arena_cap_units: what the host has made room for.  When the host has read prep's counters back it has
+// sized everything for them and neither limit can bind; in the device-driven round (speculative chain) they are
+// estimates, and a task that does not fit is REFUSED -- new_base 0: every later pass skips it, the commit takes the
+// row's growth flag back, its ops stay deferred and the host-driven loop finishes them.
+constexpr uint32_t CHUNK_NONE = 0xFFFFFFFFu;
+__device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl,
+                                               uint32_t task_budget, uint32_t chunk_cap) {
   __shared__ uint32_t l_want[N_CLASSES], l_got[N_CLASSES];
   __shared__ int32_t l_top[N_CLASSES];
+  // the two bump counters (chunk ranges, arena units) are reserved ONCE PER WORKGROUP, look-then-compare-and-swap so that
+  // they never overshoot what the host has made room for (a per-task CAS loop is quadratic in the contenders: 10^5 tasks
+  // of a young table took seconds); a workgroup whose share does not fit has all of that share refused
+  __shared__ uint32_t l_chunks, l_chunk0, l_chunk_ok;
+  __shared__ unsigned long long l_units, l_unit0;
+  __shared__ uint32_t l_unit_ok;
   const uint32_t n = aload(&ctl->n_tasks);
   for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { l_chunks = 0; l_units = 0; l_chunk_ok = 1; l_unit_ok = 1; }
     __syncthreads();
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
     uint32_t cls = 0, rank = 0;
+    bool refused = live && t >= task_budget;
+    // chunked tasks (old size > 8192 cells: the new table has exactly twice the old one's 64-cell chunks) take their
+    // range of the chunk -> task maps first
+    const bool chunked = live && !refused && grow_kind(tasks[t].old_lg) == GROW_CHUNKED;
+    uint32_t my_chunk = 0;
+    if (chunked) my_chunk = atomicAdd(&l_chunks, 1u << (tasks[t].old_lg - 6));
+    __syncthreads();
+    if (threadIdx.x == 0 && l_chunks) {
+      uint32_t cur = aload(&ctl->n_chunks);
+      for (;;) {
+        if ((uint64_t)cur + l_chunks > chunk_cap) { l_chunk_ok = 0; ctl->spec_failed = 1; break; }
+        const uint32_t prev = atomicCAS(&ctl->n_chunks, cur, cur + l_chunks);
+        if (prev == cur) { l_chunk0 = cur; break; }
+        cur = prev;
+      }
+    }
+    __syncthreads();
     if (live) {
+      GrowTask& k = tasks[t];
+      k.chunk0 = CHUNK_NONE;
+      if (chunked) {
+        if (l_chunk_ok) { k.chunk0 = l_chunk0 + my_chunk; k.chunk0_new = 2u * k.chunk0; }
+        else refused = true;
+      }
+    }
+    if (live && !refused) {
       cls = tasks[t].old_lg + 1 - ROW_FIRST_LG;
       rank = atomicAdd(&l_want[cls], 1u);
     }
@@ -1621,32 +1669,40 @@ __device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* task
       l_got[c] = got;
     }
     __syncthreads();
+    const bool fresh = live && !refused && rank >= l_got[cls];     // no retired block left for it: arena
+    unsigned long long my_unit = 0;
+    if (fresh) my_unit = atomicAdd(&l_units, (unsigned long long)block_units(tasks[t].old_lg + 1));
+    __syncthreads();
+    if (threadIdx.x == 0 && l_units) {
+      // ONE add per workgroup.  With the host's exact sizing (task_budget == all) the cap cannot bind; in the device-driven
+      // round a share that lands beyond the cap is refused and its units are simply lost to the bump pointer (the host maps
+      // past them) -- rare by construction (the estimates are 4x the previous batch), and cheaper than a compare-and-swap
+      // loop that hundreds of workgroups spin on (measured: 15 -> 85 us for this kernel)
+      l_unit0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), l_units);
+      if (l_unit0 + l_units > arena_cap_units) { l_unit_ok = 0; ctl->spec_failed = 1; if (task_budget == 0xFFFFFFFFu) ctl->arena_oom = 1; }
+    }
+    __syncthreads();
     if (live) {
       GrowTask& k = tasks[t];
-      uint64_t u;
-      if (rank < l_got[cls]) {
+      uint64_t u = 0;
+      if (refused) {
+      } else if (!fresh) {
         u = fl.list[cls][l_top[cls] - 1 - (int32_t)rank];
-      } else {
-        const uint64_t units = block_units(k.old_lg + 1);
-        u = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)units);
-        if (u + units > arena_cap_units) ctl->arena_oom = 1;   // host guarantees this never fires
+      } else if (l_unit_ok) {
+        u = l_unit0 + my_unit;
       }
+      if (u == 0) ctl->spec_failed = 1;
       k.new_base = (uint32_t)u;
       k.count = 0;
       k.dup = 0;
-      if (grow_kind(k.old_lg) == GROW_CHUNKED) {
-        uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
-        uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
-        k.chunk0 = atomicAdd(&ctl->n_chunks, oc);
-        k.chunk0_new = atomicAdd(&ctl->n_chunks_new, nc);
-      }
     }
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl) {
-  grow_plan_body(SMX_VG, ctl, tasks, arena_cap_units, fl);
+__global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl,
+                                                   uint32_t task_budget, uint32_t chunk_cap) {
+  grow_plan_body(SMX_VG, ctl, tasks, arena_cap_units, fl, task_budget, chunk_cap);
 }
 
 // chunk -> task maps, filled one wave per task
@@ -1658,9 +1714,8 @@ __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const Gro
   uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t t = wave; t < n; t += nwaves) {
     const GrowTask k = tasks[t];
-    if (grow_kind(k.old_lg) != GROW_CHUNKED) continue;
-    uint32_t oc = k.old_lg <= 6 ? 1u : 1u << (k.old_lg - 6);
-    uint32_t nc = k.old_lg + 1 <= 6 ? 1u : 1u << (k.old_lg + 1 - 6);
+    if (grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE) continue;   // (a range whose task got no block is
+    const uint32_t oc = 1u << (k.old_lg - 6), nc = 2u * oc;                          //  still mapped: the passes skip it by new_base)
     for (uint32_t c = lane; c < oc; c += 64) map_old[k.chunk0 + c] = t;
     for (uint32_t c = lane; c < nc; c += 64) map_new[k.chunk0_new + c] = t;
   }
@@ -1696,6 +1751,7 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
                                               uint32_t* l_cd) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
   const uint32_t tid = S::tid();
+  if (task->new_base == 0) return;                   // refused by the plan (scope-uniform)
   const uint32_t old_lg = task->old_lg;
   const uint32_t old_size = 1u << old_lg, new_size = 2u << old_lg, nmask = new_size - 1u;
   uint64_t* O = row_cells(arena, task->old_base);
@@ -1770,6 +1826,7 @@ __device__ __forceinline__ void grow_move_body(VGrid g, const Ctl* ctl, GrowTask
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
     uint32_t t = map_old[ch];
     GrowTask& k = tasks[t];
+    if (k.new_base == 0) continue;                 // refused by the plan (wave-uniform)
     uint32_t old_size = 1u << k.old_lg;
     uint32_t p = (ch - k.chunk0) * 64 + lane;
     uint64_t cur = 0;
@@ -1818,13 +1875,14 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
 // one wave per 64 new slots: replace the carried old-slot index by the value
 __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTask* tasks,
                                                  const uint32_t* map_new, uint8_t* arena) {
-  uint32_t nchunks = aload(&ctl->n_chunks_new);
+  uint32_t nchunks = 2u * aload(&ctl->n_chunks);    // (chunked rows: the new table has twice the old one's chunks)
   uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
   uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
     uint32_t t = map_new[ch];
     const GrowTask k = tasks[t];
+    if (k.new_base == 0) continue;
     uint32_t new_size = 2u << k.old_lg;
     uint32_t q = (ch - k.chunk0_new) * 64 + lane;
     if (q < new_size) {
@@ -1884,7 +1942,7 @@ __device__ __forceinline__ void grow_zero_body(VGrid g, const Ctl* ctl, const Gr
   uint32_t nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
     const GrowTask k = tasks[map_old[ch]];
-    if (k.dup) continue;                             // grow_fixdup_one still needs (and then zeroes) it
+    if (k.dup || k.new_base == 0) continue;          // grow_fixdup_one still needs (and then zeroes) it; refused: untouched
     const uint32_t p = (ch - k.chunk0) * 64 + lane;
     if (p < (1u << k.old_lg)) row_cells(arena, k.old_base)[p] = 0;
   }
@@ -1904,9 +1962,13 @@ __device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* ta
     if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t t = t0 + threadIdx.x;
-    const bool live = t < n;
+    bool live = t < n;
     GrowTask k = {};
     uint32_t cls = 0, rank = 0;
+    if (live && tasks[t].new_base == 0) {               // refused by the plan: the row stays as it is
+      atomicAnd(&dir[tasks[t].dslot].meta, ~META_GROW);
+      live = false;
+    }
     if (live) {
       if (tasks[t].dup) grow_fixdup_one(tasks[t], arena);
       k = tasks[t];
@@ -1963,6 +2025,25 @@ __device__ __forceinline__ void rebal_body(VGrid g, const Ctl* ctl, const uint32
 }
 __global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uint8_t* arena) {
   rebal_body(SMX_VG, ctl, rebal, dir, arena);
+}
+
+// Between two op rounds that the HOST does not separate (speculative chain): what round 0 deferred becomes the length
+// of the list the next round reads, round 0's counters are kept for the host's statistics, and the per-round part of the
+// control block starts from zero again (what ctl_reset_round does from the host).  One lane.
+__global__ void k_round_advance(Ctl* ctl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ctl->n_prev = ctl->n_defer;
+  ctl->spec_nd0 = ctl->n_defer;
+  ctl->spec_nt0 = ctl->n_tasks;
+  ctl->spec_gu0 = ctl->grow_units;
+  ctl->spec_nrebal0 = ctl->n_rebal;
+  ctl->spec_dirfull0 = ctl->dir_full;
+  for (int k = 0; k < 4; k++) ctl->spec_nkind0[k] = ctl->n_kind[k];
+  const uint32_t keep_long = ctl->n_long, keep_oom = ctl->arena_oom;
+  uint64_t* z = reinterpret_cast<uint64_t*>(ctl);
+  for (uint32_t i = 0; i < CTL_ROUND_BYTES / 8; i++) z[i] = 0;
+  ctl->n_long = keep_long;                           // (sticky for the batch: the host switches the retries to lane-per-op)
+  ctl->arena_oom = keep_oom;
 }
 
 // ---- set: duplicates of one cell inside a batch resolve highest-index-wins ----
@@ -2211,34 +2292,49 @@ constexpr uint32_t GETROW_SEG = 32768;
 
 __device__ inline uint32_t getrow_nseg(uint32_t size) { return size >= 2 * GETROW_SEG ? size / GETROW_SEG : 1u; }
 
+// `budget`: segments the caller's seg_cnt array has room for BEYOND one per noted row.  A batch may name one giant row
+// many times (a hot item requested by many callers): every occurrence is noted and would want all of its segments, so
+// the total is not bounded by the arena's size.  Occurrences are cut while the budget lasts (in list order, an
+// occurrence that does not fit does not consume); the others stay whole -- one workgroup walks the row, as before
+// the segmentation -- and need no count entry.
 __global__ __launch_bounds__(1024) void k_getrow_plan(DirSlot* dir, uint32_t dmask, const uint32_t* __restrict__ xs,
-                                                      const uint32_t* big, uint32_t* seg_start) {
+                                                      const uint32_t* big, uint32_t* seg_start, uint32_t budget) {
   __shared__ uint32_t wsum[16];
-  __shared__ uint32_t s_base;
+  __shared__ uint32_t s_base, s_extra;
   const uint32_t nbig = big[0];
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_base = 0;
+  if (threadIdx.x == 0) { s_base = 0; s_extra = 0; }
   __syncthreads();
-  for (uint32_t b0 = 0; b0 < nbig; b0 += 1024) {
-    const uint32_t b = b0 + threadIdx.x;
-    uint32_t v = 0;
-    if (b < nbig) {
-      uint4 s;
-      dir_find(dir, dmask, xs[big[1 + b]], &s);
-      v = getrow_nseg(1u << meta_lg(s.x));
-    }
-    uint32_t incl = v;                                    // inclusive scan inside the wave
+  auto block_scan = [&](uint32_t v, uint32_t carry, uint32_t* total) -> uint32_t {   // exclusive prefix over the workgroup + carry
+    uint32_t incl = v;
     for (uint32_t d = 1; d < 64; d <<= 1) {
       const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
       if (lane >= d) incl += o;
     }
+    __syncthreads();
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    uint32_t before = s_base, total = 0;
-    for (uint32_t i = 0; i < 16; i++) { const uint32_t t = wsum[i]; if (i < w) before += t; total += t; }
-    if (b < nbig) seg_start[b] = before + incl - v;
+    uint32_t before = carry, tot = 0;
+    for (uint32_t i = 0; i < 16; i++) { const uint32_t t = wsum[i]; if (i < w) before += t; tot += t; }
+    *total = tot;
+    return before + incl - v;
+  };
+  for (uint32_t b0 = 0; b0 < nbig; b0 += 1024) {
+    const uint32_t b = b0 + threadIdx.x;
+    uint32_t want = 0;
+    if (b < nbig) {
+      uint4 s;
+      dir_find(dir, dmask, xs[big[1 + b]], &s);
+      want = getrow_nseg(1u << meta_lg(s.x));
+    }
+    uint32_t tot_e = 0, tot_v = 0;
+    const uint32_t extra = want ? want - 1u : 0u;
+    const uint32_t ebefore = block_scan(extra, s_extra, &tot_e);
+    const uint32_t v = (uint64_t)ebefore + extra <= budget ? want : (want ? 1u : 0u);
+    const uint32_t start = block_scan(v, s_base, &tot_v);
+    if (b < nbig) seg_start[b] = start;
     __syncthreads();
-    if (threadIdx.x == 0) s_base += total;
+    if (threadIdx.x == 0) { s_base += tot_v; s_extra = (uint32_t)min((uint64_t)s_extra + tot_e, (uint64_t)0xffffffffu); }
     __syncthreads();
   }
   if (threadIdx.x == 0) seg_start[nbig] = s_base;

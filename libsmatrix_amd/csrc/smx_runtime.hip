@@ -17,10 +17,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -53,6 +55,16 @@ namespace {
       smx_die(b_);                                                                     \
     }                                                                                  \
   } while (0)
+
+inline void chunk_pool_trim();
+// hipMalloc that, when the device is out of memory, first gives the pooled chunks of closed matrices back (ChunkPool)
+template <typename T>
+inline void dev_malloc(T** p, size_t bytes) {
+  if (hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess) return;
+  (void)hipGetLastError();
+  chunk_pool_trim();
+  HIP_OK(hipMalloc(reinterpret_cast<void**>(p), bytes));
+}
 
 inline uint32_t blocks_for(uint64_t n, uint32_t per = 256) {
   return (uint32_t)std::max<uint64_t>(1, (n + per - 1) / per);
@@ -103,6 +115,7 @@ struct ChunkPool {
   }
 };
 inline ChunkPool& chunk_pool() { static ChunkPool* p = new ChunkPool; return *p; }     // (never destroyed: no HIP calls at exit)
+inline void chunk_pool_trim() { chunk_pool().trim(); }
 
 struct Arena {
   uint8_t* base = nullptr;
@@ -171,7 +184,13 @@ struct Arena {
         for (size_t sz = (size_t)1 << 30; sz >= ((size_t)4 << 20); sz >>= 2)
           if (sz % gran == 0 && sz <= total) { add = sz; break; }
         hipMemGenericAllocationHandle_t h;
-        if (!chunk_pool().take(device, add, &h)) HIP_OK(hipMemCreate(&h, add, &prop, 0));
+        if (!chunk_pool().take(device, add, &h) && hipMemCreate(&h, add, &prop, 0) != hipSuccess) {
+          // out of memory while chunks of closed matrices sit idle in the pool (they only fit requests of their own
+          // size): hand them back to the driver and try once more before dying
+          (void)hipGetLastError();
+          chunk_pool().trim();
+          HIP_OK(hipMemCreate(&h, add, &prop, 0));
+        }
         HIP_OK(hipMemMap(base + mapped, add, 0, h, 0));
         // Access for the new chunk only where the runtime takes a sub-range (the HIP 7.0 runtime bundled
         // with PyTorch does; there the whole-range form costs ~8 ms per mapped GB: 30-60 ms per growth of a
@@ -189,7 +208,7 @@ struct Arena {
     } else {
       size_t nb = std::max(bytes, mapped * 2);
       uint8_t* p = nullptr;
-      HIP_OK(hipMalloc(&p, nb));
+      dev_malloc(&p, nb);
       zero_async(p, nb, st);
       if (base && live) HIP_OK(hipMemcpyAsync(p, base, live, hipMemcpyDeviceToDevice, st));
       HIP_OK(hipStreamSynchronize(st));
@@ -225,7 +244,7 @@ struct DevBuf {
     if (n <= cap) return;
     if (p) HIP_OK(hipFree(p));
     size_t c = std::max<size_t>(n, cap * 2);
-    HIP_OK(hipMalloc(&p, c * sizeof(T)));
+    dev_malloc(&p, c * sizeof(T));
     cap = c;
   }
   void release() {
@@ -387,12 +406,27 @@ struct Matrix {
   bool profile = false;
   bool trace_rounds = false;            // SMATRIX_TRACE_ROUNDS=1: one stderr line per round
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  struct TimedLaunch { hipEvent_t e0, e1; uint32_t n; };
+  std::deque<TimedLaunch> get_pending;  // profiled get launches whose events have not been read yet (get_timing_resolve)
+  std::vector<hipEvent_t> ev_free;
   bool grow_fork = true;                // SMATRIX_GROW_FORK=0: everything of a growth round on the caller's stream (see grow_rows)
   hipStream_t helper = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   std::string fname;
-  bool dirty = false;                   // file mode: something changed since the file was loaded / last written
+  // file mode: something changed since the file was loaded / last written.  Set by every writer (the scalar mirror's
+  // host-side writes included, which hold no lock); whoever flushes takes it with exchange(false) BEFORE it syncs the
+  // mirror and collects the dirty rows, so a write that lands during a flush keeps the flag up for the next one.
+  std::atomic<bool> dirty{false};
+  bool in_cache_sync = false;           // the write batch in flight is the mirror's write-back (its cells were flagged when they were written)
+  // background flusher (the reference's IO thread, src/smatrix.c:929-960: dirty rows reach the file behind the caller's
+  // back, 100 ms poll :945): a timer thread that runs cache_sync + file_flush under the matrix lock every
+  // SMATRIX_FLUSH_MS (default 100; 0 = off), never more than ~1/10 of the time (the pause grows with the last flush)
+  uint64_t flush_ms = 100;
+  std::thread flusher;
+  std::mutex fl_mu;
+  std::condition_variable fl_cv;
+  bool fl_stop = false;
   CellCache cache;                      // scalar ABI: mirrored cells (see CellCache)
   DevBuf<uint64_t> row_ret;             // scalar getrow: pooled device buffer for rows that outgrow the pinned one
   uint32_t* h_row = nullptr;            // pinned: {count, spare, big[2], offsets[2] (u64)} + pairs written by the kernel itself
@@ -404,11 +438,17 @@ struct Matrix {
   // the bulk path (k_fix_*): taken in round 0 when the previous write batch deferred a large share of its ops
   bool bulk_enabled = true;             // SMATRIX_BULK=0 switches it off
   bool expect_bulk = true;              // an empty matrix creates its rows: expect it
+  uint32_t fix_share = 4;               // ... and only when at least 1/fix_share of the batch is pending (SMATRIX_BULK_SHARE)
   uint32_t fix_min = 1u << 14;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN): its fixed cost is ~6 small
                                         // launches and 3 read-backs, about two rounds of the loop it replaces
   DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped;
   uint32_t fx_dir_size = 0;             // directory size fx_cnt / fx_cur / fx_pos were laid out (and zeroed) for
   DevBuf<uint64_t> fx_excl, fx_tiles;
+  // the speculative chain (run_write): on when the previous write batch was finished by its round 1
+  bool spec_enabled = true;             // SMATRIX_SPEC=0 switches it off
+  bool spec_ready = false;
+  uint32_t spec_nd_prev = 0, spec_nt_prev = 0, spec_nk_prev[4] = {0, 0, 0, 0};   // the previous batch's round 0: deferred ops, growth tasks (by kind)
+  uint64_t spec_gu_prev = 0;            // ... and the units its growths took
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
 };
 
@@ -444,7 +484,7 @@ void ensure_free_cap(Matrix* m, uint32_t c, uint64_t extra, hipStream_t s) {
   if (need <= m->fl.cap[c]) return;
   const uint64_t ncap = std::max<uint64_t>(need, (uint64_t)m->fl.cap[c] * 2);
   uint32_t* np = nullptr;
-  HIP_OK(hipMalloc(&np, ncap * sizeof(uint32_t)));
+  dev_malloc(&np, ncap * sizeof(uint32_t));
   if (have) HIP_OK(hipMemcpyAsync(np, m->fl.list[c], have * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   HIP_OK(hipStreamSynchronize(s));
   if (m->fl.list[c]) HIP_OK(hipFree(m->fl.list[c]));
@@ -478,7 +518,7 @@ void grow_directory(Matrix* m, uint32_t factor, hipStream_t s) {
   if (ns64 > (1ull << 31)) smx_die("directory too large");
   uint32_t ns = (uint32_t)ns64;
   DirSlot* nd = nullptr;
-  HIP_OK(hipMalloc(&nd, (size_t)ns * sizeof(DirSlot)));
+  dev_malloc(&nd, (size_t)ns * sizeof(DirSlot));
   zero_async(nd, (size_t)ns * sizeof(DirSlot), s);
   hipLaunchKernelGGL(k_dir_rehash, dim3(blocks_for(m->dir_size)), dim3(256), 0, s, m->d_dir,
                      m->dir_size, nd, ns - 1);
@@ -562,18 +602,51 @@ void account_kernel_time(Matrix* m, int op, uint32_t n) {
   m->st.kernel_ops[op] += n;
 }
 
-void grow_rows(Matrix* m, hipStream_t s) {
-  const uint32_t nt = m->h_ctl->n_tasks;
-  const uint64_t gu = m->h_ctl->grow_units;
+// The get kernel is ONE asynchronous launch: waiting for its stop event right behind it (as the write path may, which
+// has just read its counters back anyway) would turn every profiled get into a synchronous call and expose the next
+// call's launch latency -- 0.1-0.3 ms per step on a slow host (round 3: the kernel spans of a bench step summed to
+// 2.27 ms, its wall time was 2.6).  So get launches are timed with event PAIRS from a small ring that are read later:
+// when the ring wraps (that launch finished long ago), at smatrix_stats() and when profiling is switched off.
+void get_timing_resolve(Matrix* m, size_t keep) {
+  while (m->get_pending.size() > keep) {
+    Matrix::TimedLaunch t = m->get_pending.front();
+    m->get_pending.pop_front();
+    float ms = 0;
+    HIP_OK(hipEventSynchronize(t.e1));
+    HIP_OK(hipEventElapsedTime(&ms, t.e0, t.e1));
+    m->st.kernel_ms[OP_GET] += ms;
+    m->st.kernel_launches[OP_GET]++;
+    m->st.kernel_ops[OP_GET] += t.n;
+    m->ev_free.push_back(t.e0);
+    m->ev_free.push_back(t.e1);
+  }
+}
+hipEvent_t get_timing_event(Matrix* m) {
+  if (m->ev_free.empty()) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    return e;
+  }
+  hipEvent_t e = m->ev_free.back();
+  m->ev_free.pop_back();
+  return e;
+}
+
+// nt / gu / nk: what prep has counted (read back), or -- `spec` -- the host's ESTIMATES for a round whose counters it has
+// not read: every buffer is sized for them, the launches get grids for them (the kernels loop over the device-side
+// counts), and k_grow_plan refuses what does not fit.
+void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_t* nk, bool spec) {
   ensure_arena_free(m, gu, s);
   // chunk bounds: a table of 2^lg cells has max(1, 2^lg/64) chunks; units = 2^lg/16
   m->map_new.need((size_t)nt + gu / 4 + 1);
   m->map_old.need((size_t)nt + gu / 8 + 1);
   const uint64_t cap_units = m->arena.mapped / UNIT_BYTES;
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, nt, s);     // every task retires one block
+  // (spec: the arena holds gu units beyond the host's mirror of the bump pointer -- row creation in prep may have taken
+  //  some of the slack ensure_arena_free was asked for, hence the cap is what is mapped, checked per allocation)
   hipLaunchKernelGGL(k_grow_plan, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
-                     m->d_ctl, m->tasks.p, cap_units, m->fl);
-  const uint32_t* nk = m->h_ctl->n_kind;
+                     m->d_ctl, m->tasks.p, cap_units, m->fl, spec ? nt : 0xFFFFFFFFu,
+                     spec ? (uint32_t)std::min<uint64_t>(m->map_old.cap, m->map_new.cap / 2) : 0xFFFFFFFFu);
   const uint32_t n_chunked = nk[GROW_CHUNKED];
   // the chunked passes of the large rows touch other rows than the in-LDS rehashes: they run on a helper stream beside
   // them, from the plan on (non-blocking stream + events: the caller's stream may be the legacy default stream, which a
@@ -613,7 +686,7 @@ void grow_rows(Matrix* m, hipStream_t s) {
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
   HIP_OK(hipGetLastError());
-  if (m->trace_rounds && nt > 1000) {      // who grows?  (cells moved, by log2 of the old row size)
+  if (m->trace_rounds && nt > 1000 && !spec) {      // who grows?  (cells moved, by log2 of the old row size)
     std::vector<GrowTask> ht(nt);
     HIP_OK(hipMemcpyAsync(ht.data(), m->tasks.p, (size_t)nt * sizeof(GrowTask), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -625,7 +698,7 @@ void grow_rows(Matrix* m, hipStream_t s) {
     fprintf(stderr, "\n");
   }
   m->arena_next += gu;   // upper bound until the next readback (recycled blocks take nothing from the arena)
-  m->st.rows_grown += nt;
+  if (!spec) m->st.rows_grown += nt;
 }
 
 // The bulk path of a write batch (smx_kernels.hpp "the bulk path"): `nd` deferred ops in `dl`; returns how many were
@@ -702,10 +775,22 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
 }
 
 // The write-batch round loop (device pointers).
+//
+// Steady state has a fixed shape: round 0 defers ~1 % of the batch (new keys of rows that stand at the reference's
+// threshold), prep flags those rows, they double, round 1 applies the deferred ops, nothing is left.  Driven from the
+// host that is two read-backs and a dozen small launches issued one by one behind the first read-back -- the GPU waits
+// for each launch packet (round 3: the kernels between the end of round 0 and the get kernel add up to 0.30 ms, the
+// span is 0.42-0.55 ms).  When the previous batch had that shape the whole sequence is therefore enqueued AT ONCE
+// ("speculative chain"): op kernel, prep, every growth pass with grids and buffers sized from the previous batch's
+// counts (x2), k_round_advance, the retry over the device-side list, prep again -- and ONE read-back.  Nothing is
+// guessed about the data: the kernels loop over the device-side counts, and a growth task that does not fit the
+// estimates is refused by k_grow_plan (its row stays as it is, its ops stay deferred), so whatever is left after the
+// chain -- refused tasks, rows that double twice in one batch, a full directory -- is finished by the host-driven loop
+// below exactly as before.  SMATRIX_SPEC=0 switches the chain off.
 void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t* y,
                const uint32_t* v, uint32_t* out, hipStream_t s) {
   if (n == 0) return;
-  m->dirty = true;
+  if (!m->in_cache_sync) m->dirty = true;
   m->defer[0].need(n);
   m->defer[1].need(n);
   if (op == OP_SET) m->cellp.need((size_t)n + AGG_TILE);
@@ -721,20 +806,27 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   bool timed0 = m->profile;
   uint32_t stalled = 0, rows_before = m->dir_used;
   m->long_probes = false;
+  uint32_t rounds_this_batch = 0;
+  // the chain is tried when the previous write batch was finished by its round 1 (or by the chain itself)
+  bool chain = m->spec_enabled && m->spec_ready && !m->expect_bulk && n >= m->agg_min && m->dbg_after == 0;
   for (uint32_t round = 0;; round++) {
     // the loop ends when nothing is deferred; it is abandoned only when rounds stop making PROGRESS (a fixed cap
     // would turn a slow but legal batch -- many new rows contending for one directory slot -- into an abort)
     if (stalled > 8) smx_die("write batch did not converge (corrupt row table?)");
     const uint32_t dir_limit = m->dir_size / 2;
     const uint32_t room = dir_limit > m->dir_used ? dir_limit - m->dir_used : 0;
-    ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
     // at most one growth task / re-partition per row, and only rows named by a deferred op
     m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
     m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
     m->klist.need(3 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
-    ctl_reset_round(m, s);
     uint32_t* dl = m->defer[round & 1].p;
+    const bool chained = chain && round == 0;
+    // estimates for the chain's growth round: four times what the previous batch needed (k_grow_plan refuses the rest)
+    const uint32_t est_nt = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nt_prev, 1u << 16), std::min<uint64_t>(cur_n, m->dir_size));
+    const uint64_t est_gu = std::max<uint64_t>(2 * m->spec_gu_prev, 1ull << 20);
+    ensure_arena_free(m, std::min<uint64_t>(cur_n, room) + (chained ? est_gu : 0), s);
+    ctl_reset_round(m, s);
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
 #if defined(SMX_AGG_DBG) && SMX_AGG_DBG == 5
     // measurement build "inserts without tickets": rows overfill and their deferred ops never converge -- only the
@@ -745,7 +837,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       break;
     }
 #endif
-    if (round == 0 && m->bulk_enabled && m->expect_bulk && op != OP_GET && n >= m->fix_min) {
+    if (round == 0 && !chained && m->bulk_enabled && m->expect_bulk && op != OP_GET && n >= m->fix_min) {
       // the previous batch deferred a large share of its ops (bulk load, young matrix): look at this one's count
       // before prep -- one extra read-back, only in this regime -- and group a large remainder by row instead of
       // walking it through a round per doubling
@@ -753,8 +845,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       if (timed0) { account_kernel_time(m, op, n); timed0 = false; }
       const uint32_t nd0 = m->h_ctl->n_defer;
       m->expect_bulk = (uint64_t)nd0 * 8 >= n;
-      if (nd0 >= m->fix_min && nd0 < 0x80000000u) {           // (k_fix_scatter keeps a flag in bit 31 of a position)
+      // worth it when a LARGE share of the batch is pending (bulk loads, the first batch of a matrix: every op names a
+      // row that does not exist yet).  At 10-15 % -- batches 1 and 2 of config 2 -- grouping costs more than the rounds
+      // it replaces (round 3, same box: step 1 7.2 -> 3.9 ms, step 2 5.0 -> 3.2 ms without it): SMATRIX_BULK_SHARE
+      if (nd0 >= m->fix_min && nd0 < 0x80000000u && (uint64_t)nd0 * m->fix_share >= n) {   // (k_fix_scatter keeps a flag in bit 31 of a position)
         m->st.rounds++;
+        rounds_this_batch++;
         m->st.deferred_ops += nd0;
         m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
         uint32_t* dl2 = m->defer[1].p;
@@ -768,18 +864,73 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         idx = dl2;                       // what was handed back sits in defer[1]: the next round must write defer[0],
         cur_n = nd2;                     // so it is numbered 2
         round++;
+        rounds_this_batch += 2;          // (not the steady shape: no chain for the next batch)
         continue;
       }
     }
-    hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
-                       m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
-                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
-                       m->rebal.p, m->fl, m->in_stride, 0u);
+    const auto launch_prep = [&](const uint32_t* list) {
+      hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
+                         m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
+                         (uint64_t)(m->arena.mapped / UNIT_BYTES), list, x, y, m->tasks.p, m->klist.p, m->klist_cap,
+                         m->rebal.p, m->fl, m->in_stride, 0u);
+    };
+    launch_prep(dl);
     HIP_OK(hipGetLastError());
+    uint32_t nd_chain0 = 0;
+    if (chained) {
+      // ---- the rest of the chain: growth for the rows round 0's prep flagged, the retry, its prep -- no read-back between
+      const uint32_t est_nk[4] = {std::max<uint32_t>(2 * m->spec_nk_prev[0], 4096), std::max<uint32_t>(2 * m->spec_nk_prev[1], 1024),
+                                  std::max<uint32_t>(2 * m->spec_nk_prev[2], 256), std::max<uint32_t>(2 * m->spec_nk_prev[3], 64)};
+      const uint64_t host_next = m->arena_next;
+      grow_rows(m, s, est_nt, est_gu, est_nk, true);
+      m->arena_next = host_next;                              // (the mirror is refreshed by the read-back below)
+      hipLaunchKernelGGL(k_rebal, dim3(64), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
+      hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl);
+      // the retry: lane per op over the device-side list (its length is ctl->n_prev), grid for 4x the previous batch's
+      const uint32_t est_nd = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n);
+      uint32_t* dl1 = m->defer[1].p;
+      const dim3 rgrid(std::min<uint32_t>(blocks_for(est_nd), 16384));
+      switch (op) {
+        case OP_SET:  hipLaunchKernelGGL((k_apply<OP_SET>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+        case OP_INCR: hipLaunchKernelGGL((k_apply<OP_INCR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+        default:      hipLaunchKernelGGL((k_apply<OP_DECR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+      }
+      launch_prep(dl1);
+      HIP_OK(hipGetLastError());
+      dl = dl1;
+    }
     ctl_read(m, s);
     if (timed0 && round == 0) account_kernel_time(m, op, n);
     m->st.rounds++;
-    if (m->trace_rounds) {
+    rounds_this_batch++;
+    if (chained) {
+      // bookkeeping of the round the host did not see, then on as if round 1 had just been read back
+      const Ctl& c = *m->h_ctl;
+      nd_chain0 = c.spec_nd0;
+      m->expect_bulk = (uint64_t)nd_chain0 * 8 >= n;
+      m->st.spec_chains++;
+      if (nd_chain0) {
+        m->st.rounds++;
+        rounds_this_batch++;
+        m->st.deferred_ops += nd_chain0;
+        m->st.rows_grown += c.spec_nt0;                        // (refused tasks are counted again when they do grow: rare)
+        m->st.rows_rebalanced += c.spec_nrebal0;
+        m->spec_nd_prev = nd_chain0; m->spec_nt_prev = c.spec_nt0; m->spec_gu_prev = c.spec_gu0;
+        for (int k = 0; k < 4; k++) m->spec_nk_prev[k] = c.spec_nkind0[k];
+      }
+      if (c.spec_failed) {
+        m->st.spec_refused++;
+        const uint32_t zero = 0;
+        HIP_OK(hipMemcpyAsync(&m->d_ctl->spec_failed, &zero, 4, hipMemcpyHostToDevice, s));
+      }
+      if (m->trace_rounds)
+        fprintf(stderr, "[smatrix] batch %llu chain: ops=%u deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u\n",
+                (unsigned long long)m->st.batches, cur_n, nd_chain0, c.spec_nt0, (unsigned long long)c.spec_gu0, c.spec_nrebal0,
+                c.spec_failed, c.n_defer, c.n_tasks, c.dir_used);
+      if (nd_chain0 == 0) break;                               // round 0 deferred nothing: the rest of the chain ran empty
+      cur_n = nd_chain0;
+      round = 1;
+    } else if (m->trace_rounds) {
       static thread_local double t_prev = 0;
       struct timespec ts;
       clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -793,6 +944,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = m->h_ctl->n_defer;
     if (round == 0) m->expect_bulk = (uint64_t)nd * 8 >= n;
+    if (round == 1 && !chained && nd == 0) {
+      // the steady shape: remember what round 0 needed -- the next batch's chain is sized from it
+      m->spec_nd_prev = cur_n;
+    }
     if (nd == 0) break;
     if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
@@ -800,7 +955,11 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     stalled = progress ? 0 : stalled + 1;
     rows_before = m->dir_used;
     m->st.deferred_ops += nd;
-    if (m->h_ctl->n_tasks) grow_rows(m, s);
+    if (round == 0) {
+      m->spec_nt_prev = m->h_ctl->n_tasks; m->spec_gu_prev = m->h_ctl->grow_units;
+      for (int k = 0; k < 4; k++) m->spec_nk_prev[k] = m->h_ctl->n_kind[k];
+    }
+    if (m->h_ctl->n_tasks) grow_rows(m, s, m->h_ctl->n_tasks, m->h_ctl->grow_units, m->h_ctl->n_kind, false);
     if (m->h_ctl->n_rebal) {
       hipLaunchKernelGGL(k_rebal, dim3(std::min<uint32_t>(blocks_for(m->h_ctl->n_rebal, 64), 1024)), dim3(64), 0, s,
                          m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
@@ -812,6 +971,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     idx = dl;
     cur_n = nd;
   }
+  // the chain is for batches of the steady shape: finished by round 1 (host-driven: rounds 0 and 1; chained: the same two)
+  m->spec_ready = rounds_this_batch <= 2;
 
   if (op == OP_SET && m->set_entries) {
     // highest-index-wins across tiles, over the winners of k_set_fold only (locate also clears the value word)
@@ -839,8 +1000,18 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
 void run_get(Matrix* m, uint32_t n, const uint32_t* x, const uint32_t* y, uint32_t* out,
              hipStream_t s) {
   if (n == 0) return;
+  if (!m->profile) {
+    launch_apply_op(m, OP_GET, s, n, nullptr, x, y, nullptr, out, nullptr);
+    return;
+  }
+  get_timing_resolve(m, 15);
+  Matrix::TimedLaunch t{get_timing_event(m), get_timing_event(m), n};
+  HIP_OK(hipEventRecord(t.e0, s));
+  m->profile = false;                                   // (launch_apply_op would record the shared pair of the write path)
   launch_apply_op(m, OP_GET, s, n, nullptr, x, y, nullptr, out, nullptr);
-  if (m->profile) account_kernel_time(m, OP_GET, n);
+  m->profile = true;
+  HIP_OK(hipEventRecord(t.e1, s));
+  m->get_pending.push_back(t);
 }
 
 Matrix* M(smatrix_t* self) { return static_cast<Matrix*>(self->impl); }
@@ -867,6 +1038,7 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
   // thread writes dirty rows behind the caller's back all the time, src/smatrix.c:929-960; here it is a checkpoint)
   if (op != OP_GET && m->flush_every && self->fd && m->st.batches % m->flush_every == 0) {
     HIP_OK(hipStreamSynchronize(s));
+    m->dirty = false;
     file_flush(self, m, false);
   }
 }
@@ -888,7 +1060,9 @@ void cache_sync(Matrix* m, bool drop) {
   const uint32_t keep = m->in_stride;
   m->in_stride = 1;
   const uint64_t batches = m->st.batches;
+  m->in_cache_sync = true;
   run_write(m, OP_SET, (uint32_t)k, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);   // synchronises (set resolves duplicates last)
+  m->in_cache_sync = false;
   m->st.batches = batches;                                                     // bookkeeping of the caller's batches only
   m->in_stride = keep;
   m->cache.flushes++;
@@ -900,6 +1074,39 @@ void cache_sync(Matrix* m, bool drop) {
 // ---- persistence (src/smatrix.c:30-72 file format) ---------------------------------
 #include "smx_file.inc"
 
+namespace {
+void flusher_main(smatrix_t* self, Matrix* m) {
+  using clock = std::chrono::steady_clock;
+  const auto period = std::chrono::milliseconds(m->flush_ms);
+  std::unique_lock<std::mutex> l(m->fl_mu);
+  auto next = clock::now() + period;
+  while (!m->fl_stop) {
+    m->fl_cv.wait_until(l, next, [&] { return m->fl_stop; });
+    if (m->fl_stop) break;
+    l.unlock();
+    auto pause = period;
+    if (m->dirty.load()) {
+      const auto t0 = clock::now();
+      {
+        set_device(m);
+        std::lock_guard<std::mutex> g(m->mu);
+        if (m->dirty.exchange(false)) {
+          cache_sync(m, false);
+          file_flush(self, m, false);
+          m->st.file_bg_flushes++;
+        }
+      }
+      // a flush holds the matrix lock: keep it to about a tenth of the time (a 4 s flush of a 27 GB matrix is
+      // followed by 40 s without one; small matrices stay at the period)
+      const auto took = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0);
+      pause = std::max(period, took * 10);
+    }
+    l.lock();
+    next = clock::now() + pause;
+  }
+}
+}  // namespace
+
 // ---- C ABI -----------------------------------------------------------------------
 extern "C" {
 
@@ -909,8 +1116,10 @@ int smatrix_flush(smatrix_t* self) {
   if (m->fname.empty() || !self->fd) return 0;
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
-  cache_sync(m, false);
-  if (m->dirty) file_flush(self, m, false);
+  if (m->dirty.exchange(false)) {
+    cache_sync(m, false);
+    file_flush(self, m, false);
+  }
   return 0;
 }
 
@@ -951,9 +1160,9 @@ smatrix_t* smatrix_open(const char* fname) {
   // a BLOCKING stream: ordered against the legacy default stream, so host-pointer calls (this stream)
   // and device-pointer calls with hip_stream == NULL (the default stream) never overlap each other
   HIP_OK(hipStreamCreate(&m->stream));
-  HIP_OK(hipMalloc(&m->d_ctl, sizeof(Ctl)));
+  dev_malloc(&m->d_ctl, sizeof(Ctl));
   HIP_OK(hipHostMalloc(&m->h_ctl, sizeof(Ctl)));
-  HIP_OK(hipMalloc(&m->d_small, 64));
+  dev_malloc(&m->d_small, 64);
   HIP_OK(hipHostMalloc(&m->h_small, 64));
   HIP_OK(hipHostMalloc(&m->h_row, 32 + (size_t)SCALAR_ROW_PAIRS_ALLOC * 8));
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
@@ -966,9 +1175,14 @@ smatrix_t* smatrix_open(const char* fname) {
     HIP_OK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
   }
   m->dir_size = 65536;                               // SMATRIX_CMAP_INITIAL_SIZE, src/smatrix.h:24
-  HIP_OK(hipMalloc(&m->d_dir, (size_t)m->dir_size * sizeof(DirSlot)));
+  dev_malloc(&m->d_dir, (size_t)m->dir_size * sizeof(DirSlot));
   zero_async(m->d_dir, (size_t)m->dir_size * sizeof(DirSlot), m->stream);
   m->arena.init(dev, 4u << 20, m->stream);
+  // the growth passes' buffers start at sizes a steady-state batch of 2^24 ops needs (30 MB in all), so that the first
+  // batches that use them do not stop to allocate (a hipFree inside a timed step is a device-wide sync)
+  m->map_old.need((size_t)1 << 20);
+  m->map_new.need((size_t)1 << 21);
+  for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, c < 12 ? 1u << 18 : 1u << 12, m->stream);
   HIP_OK(hipStreamSynchronize(m->stream));
   ctl_push_persistent(m, m->stream);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2>),
@@ -978,10 +1192,13 @@ smatrix_t* smatrix_open(const char* fname) {
   m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* a = getenv("SMATRIX_DBG_AFTER")) m->dbg_after = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
+  if (const char* a = getenv("SMATRIX_SPEC")) m->spec_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
+  if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_FSYNC")) m->file_fsync = *a == '1';
   if (const char* a = getenv("SMATRIX_COMPACT_AT_CLOSE")) m->compact_at_close = *a == '1';
   if (const char* a = getenv("SMATRIX_FLUSH_EVERY")) m->flush_every = strtoull(a, nullptr, 10);
+  if (const char* a = getenv("SMATRIX_FLUSH_MS")) m->flush_ms = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
@@ -995,6 +1212,7 @@ smatrix_t* smatrix_open(const char* fname) {
       smatrix_close(self);
       return nullptr;
     }
+    if (m->flush_ms) m->flusher = std::thread(flusher_main, self, m);
   }
   refresh_public(self);
   return self;
@@ -1006,11 +1224,16 @@ void smatrix_close(smatrix_t* self) {
   Matrix* m = M(self);
   if (m) {
     set_device(m);
+    if (m->flusher.joinable()) {                       // (it may be inside a flush: close waits for it, then does the last one)
+      { std::lock_guard<std::mutex> l(m->fl_mu); m->fl_stop = true; }
+      m->fl_cv.notify_all();
+      m->flusher.join();
+    }
     {
       std::lock_guard<std::mutex> g(m->mu);
       cache_sync(m, true);
       if (!m->fname.empty() && self->fd && m->compact_at_close) file_compact(self, m);
-      else if (!m->fname.empty() && self->fd && m->dirty) file_flush(self, m);   // a matrix that was only read has nothing to persist
+      else if (!m->fname.empty() && self->fd && m->dirty.exchange(false)) file_flush(self, m);   // a matrix that was only read has nothing to persist
       (void)hipStreamSynchronize(m->stream);
       PhaseClock clk(m->trace_rounds, "close");
       m->arena.destroy();
@@ -1028,6 +1251,8 @@ void smatrix_close(smatrix_t* self) {
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
+      get_timing_resolve(m, 0);
+      for (hipEvent_t e : m->ev_free) (void)hipEventDestroy(e);
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
       if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
@@ -1084,6 +1309,7 @@ int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* 
 int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, const uint32_t* y,
                         const uint32_t* v, uint32_t* out) {
   if (n == 0) return 0;
+  if (n >= (1ull << 32)) smx_die("batch too large (n must be < 2^32)");     // before anything is staged or copied
   Matrix* m = M(self);
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
@@ -1154,13 +1380,16 @@ namespace {
 // the noted (large) rows of a getrow launch: plan their segments, count the cut rows' segments, write
 void launch_getrow_big(Matrix* m, hipStream_t s, uint32_t n, uint32_t grid, const uint32_t* x, const uint64_t* off,
                        uint64_t* ret, uint32_t* counts, const uint32_t* big) {
-  // seg: [0 .. n] first segment of each noted row, then one count per segment (a row table of c cells has at most
-  // c / GETROW_SEG segments, the arena holds mapped / 8 cells)
-  const size_t segs = (size_t)n + m->arena.mapped / 8 / GETROW_SEG + 2;
+  // seg: [0 .. n] first segment of each noted row, then one count per segment.  Every noted occurrence of a row has
+  // one segment; `budget` more are there for cutting giant rows (all DISTINCT rows together have at most
+  // mapped / 8 / GETROW_SEG of them; a batch that names one giant row over and over runs out of budget and walks the
+  // later occurrences whole, k_getrow_plan -- ADVICE r2: the array used to be overrun in that case)
+  const uint32_t budget = (uint32_t)std::min<uint64_t>(m->arena.mapped / 8 / GETROW_SEG + 2, 1u << 24);
+  const size_t segs = (size_t)n + budget;
   m->seg.need((size_t)n + 1 + segs);
   uint32_t* seg_start = m->seg.p;
   uint32_t* seg_cnt = m->seg.p + n + 1;
-  hipLaunchKernelGGL(k_getrow_plan, dim3(1), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, x, big, seg_start);
+  hipLaunchKernelGGL(k_getrow_plan, dim3(1), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, x, big, seg_start, budget);
   hipLaunchKernelGGL(k_getrow_big<true>, dim3(grid), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
                      x, off, ret, counts, big, seg_start, seg_cnt);
   hipLaunchKernelGGL(k_getrow_big<false>, dim3(grid), dim3(1024), 0, s, m->d_dir, m->dir_size - 1, m->arena.base,
@@ -1246,11 +1475,11 @@ int smatrix_cf_neighbors_batch(smatrix_t* self, size_t n, const uint32_t* items,
   uint32_t *d_items = nullptr, *d_ids = nullptr, *d_counts = nullptr;
   uint64_t* d_off = nullptr;
   double* d_scores = nullptr;
-  HIP_OK(hipMalloc(&d_items, n * 4));
-  HIP_OK(hipMalloc(&d_off, (n + 1) * 8));
-  HIP_OK(hipMalloc(&d_counts, n * 4));
-  HIP_OK(hipMalloc(&d_ids, std::max<uint64_t>(total, 1) * 4));
-  HIP_OK(hipMalloc(&d_scores, std::max<uint64_t>(total, 1) * 8));
+  dev_malloc(&d_items, n * 4);
+  dev_malloc(&d_off, (n + 1) * 8);
+  dev_malloc(&d_counts, n * 4);
+  dev_malloc(&d_ids, std::max<uint64_t>(total, 1) * 4);
+  dev_malloc(&d_scores, std::max<uint64_t>(total, 1) * 8);
   HIP_OK(hipMemset(d_ids, 0, std::max<uint64_t>(total, 1) * 4));        // slots beyond a row's count read 0
   HIP_OK(hipMemset(d_scores, 0, std::max<uint64_t>(total, 1) * 8));
   HIP_OK(hipMemcpy(d_items, items, n * 4, hipMemcpyHostToDevice));
@@ -1370,8 +1599,11 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
         keys.reserve(dev.size());
         for (ScalarReq* r : dev) keys.push_back((uint64_t)r->x << 32 | r->y);
         std::sort(keys.begin(), keys.end());
+        // (not when the group held a y = 0 write: it may have turned a row's (0,v) cell into an empty one and cut the
+        //  probe chain of a key an earlier kind of the same group touched -- the mirror would then vouch for a cell
+        //  the reference no longer finds)
         for (ScalarReq* r : dev) {
-          if (r->op == OP_GET) continue;
+          if (r->op == OP_GET || y0_write) continue;
           const uint64_t key = (uint64_t)r->x << 32 | r->y;
           auto range = std::equal_range(keys.begin(), keys.end(), key);
           if (range.second - range.first == 1) m->cache.put(r->x, r->y, r->result);
@@ -1475,10 +1707,10 @@ int smatrix_cf_topk_batch(smatrix_t* self, size_t n, const uint32_t* items, uint
   set_device(m);
   uint32_t *d_items = nullptr, *d_ids = nullptr, *d_counts = nullptr;
   double* d_scores = nullptr;
-  HIP_OK(hipMalloc(&d_items, n * 4));
-  HIP_OK(hipMalloc(&d_counts, n * 4));
-  HIP_OK(hipMalloc(&d_ids, n * k * 4));
-  HIP_OK(hipMalloc(&d_scores, n * k * 8));
+  dev_malloc(&d_items, n * 4);
+  dev_malloc(&d_counts, n * 4);
+  dev_malloc(&d_ids, n * k * 4);
+  dev_malloc(&d_scores, n * k * 8);
   HIP_OK(hipMemset(d_ids, 0, n * k * 4));
   HIP_OK(hipMemset(d_scores, 0, n * k * 8));
   HIP_OK(hipMemcpy(d_items, items, n * 4, hipMemcpyHostToDevice));
@@ -1533,9 +1765,9 @@ int smatrix_cf_import_sessions(smatrix_t* self, size_t n_sessions, const uint64_
   if (total == 0) return 0;
   uint64_t *d_off = nullptr, *d_op = nullptr;
   uint32_t* d_ids = nullptr;
-  HIP_OK(hipMalloc(&d_off, (n_sessions + 1) * 8));
-  HIP_OK(hipMalloc(&d_op, (n_sessions + 1) * 8));
-  HIP_OK(hipMalloc(&d_ids, std::max<uint64_t>(n_ids, 1) * 4));
+  dev_malloc(&d_off, (n_sessions + 1) * 8);
+  dev_malloc(&d_op, (n_sessions + 1) * 8);
+  dev_malloc(&d_ids, std::max<uint64_t>(n_ids, 1) * 4);
   std::vector<uint64_t> rel(n_sessions + 1);
   for (size_t i = 0; i <= n_sessions; i++) rel[i] = offsets[i] - offsets[0];
   HIP_OK(hipMemcpy(d_off, rel.data(), (n_sessions + 1) * 8, hipMemcpyHostToDevice));
@@ -1565,7 +1797,9 @@ void smatrix_release_cached_memory(void) { chunk_pool().trim(); }
 // ---- introspection -------------------------------------------------------------------
 void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   Matrix* m = M(self);
+  set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
+  get_timing_resolve(m, 0);
   m->st.rows = m->dir_used;
   m->st.dir_slots = m->dir_size;
   m->st.arena_units = m->arena_next;
@@ -1583,6 +1817,7 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
 void smatrix_profile(smatrix_t* self, int on) {
   Matrix* m = M(self);
   std::lock_guard<std::mutex> g(m->mu);
+  get_timing_resolve(m, 0);
   m->profile = on != 0;
   for (int i = 0; i < 4; i++) {
     m->st.kernel_ms[i] = 0;
@@ -1677,8 +1912,8 @@ size_t smatrix_displaced_rows(smatrix_t* self, uint32_t rank, uint32_t nshards, 
   std::lock_guard<std::mutex> g(m->mu);
   uint32_t *d_out = nullptr, *d_cnt = nullptr;
   const uint32_t c = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
-  HIP_OK(hipMalloc(&d_out, std::max<size_t>(c, 1) * 4));
-  HIP_OK(hipMalloc(&d_cnt, 4));
+  dev_malloc(&d_out, std::max<size_t>(c, 1) * 4);
+  dev_malloc(&d_cnt, 4);
   HIP_OK(hipMemsetAsync(d_cnt, 0, 4, m->stream));
   hipLaunchKernelGGL(k_displaced_rows, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, m->stream,
                      m->d_dir, m->dir_size, rank, nshards, d_out, c, d_cnt);
@@ -1736,7 +1971,7 @@ int smx_stream_fill_device(smx_stream_t* st, uint64_t first, size_t n, uint32_t*
   if (n == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   if (st->dist == SMX_DIST_ZIPF && !st->d_cdf) {
-    HIP_OK(hipMalloc(&st->d_cdf, (size_t)st->n_ids * sizeof(double)));
+    dev_malloc(&st->d_cdf, (size_t)st->n_ids * sizeof(double));
     HIP_OK(hipMemcpy(st->d_cdf, st->cdf, (size_t)st->n_ids * sizeof(double), hipMemcpyHostToDevice));
   }
   hipLaunchKernelGGL(k_stream_fill, dim3(blocks_for(n)), dim3(256), 0, s, st->dist, st->seed,

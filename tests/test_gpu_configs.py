@@ -298,13 +298,14 @@ def test_native_router_one_rank(G, oracle_mod, tmp_path, monkeypatch, over_rccl)
     back.close(); o.close()
 
 
-def test_incremental_flush_writes_dirty_rows_only(G, oracle_mod, tmp_path):
+def test_incremental_flush_writes_dirty_rows_only(G, oracle_mod, tmp_path, monkeypatch):
     """Persistence the reference's way (src/smatrix.c:418-496, :744-788): smatrix_flush writes the rows that changed
     since the last flush -- in place when the table kept its size, as a fresh block with a re-pointed CMAP entry when
     it grew, as a new CMAP entry when the row is new -- and nothing else; a process that dies without smatrix_close
     leaves the state of the last flush (copy of the file taken while the matrix is still open); every stage is read
     back by the oracle (and by the compiled reference where present) and by this library's own loader."""
     import shutil
+    monkeypatch.setenv("SMATRIX_FLUSH_MS", "0")              # explicit flushes only: the counts below are exact
     rng = np.random.default_rng(17)
     path = str(tmp_path / "inc.smx")
     g, o = G(path), oracle_mod.Oracle()

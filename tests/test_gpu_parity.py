@@ -370,6 +370,7 @@ def test_bulk_path_groups_deferred_ops_by_row(G, oracle_mod, monkeypatch):
     handed back to the round loop) -- values, per-key return multisets, row sizes and rowlens are the oracle's and the
     tables are valid probe layouts."""
     monkeypatch.setenv("SMATRIX_BULK_MIN", "1")
+    monkeypatch.setenv("SMATRIX_BULK_SHARE", "1000000000")      # whatever share of the batch is pending
     rng = np.random.default_rng(41)
     g, o = G(), oracle_mod.Oracle()
     for rnd, (op, n, nx, ny) in enumerate(((2, 40000, 3000, 1 << 20), (2, 60000, 3500, 1 << 20), (3, 30000, 3500, 1 << 20),
@@ -912,6 +913,7 @@ def test_hypothesis_small_sequences_vs_oracle(G, oracle_mod, monkeypatch, bulk_m
     from hypothesis import given, settings, strategies as st, HealthCheck
     if bulk_min:
         monkeypatch.setenv("SMATRIX_BULK_MIN", bulk_min)
+        monkeypatch.setenv("SMATRIX_BULK_SHARE", "1000000000")
 
     ids = st.sampled_from([0, 1, 2, 3, 16, 17, 32, 48, 64, 5, 21, 0xFFFFFFFF, 0x80000000])
     vals = st.sampled_from([0, 1, 2, 7, 0xFFFFFFFF])
