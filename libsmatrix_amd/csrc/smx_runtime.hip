@@ -971,8 +971,9 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     idx = dl;
     cur_n = nd;
   }
-  // the chain is for batches of the steady shape: finished by round 1 (host-driven: rounds 0 and 1; chained: the same two)
-  m->spec_ready = rounds_this_batch <= 2;
+  // the chain is for batches near the steady shape (a few rounds: whatever its rounds 0 and 1 leave is finished by the
+  // host-driven loop at no extra cost); young tables with many rounds per batch stay host-driven
+  m->spec_ready = rounds_this_batch <= 4;
 
   if (op == OP_SET && m->set_entries) {
     // highest-index-wins across tiles, over the winners of k_set_fold only (locate also clears the value word)
