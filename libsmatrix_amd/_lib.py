@@ -98,6 +98,14 @@ def load():
         "smatrix_shard_set_placement": (C.c_int, [V, V, V, C.c_uint32]),
         "smatrix_shard_apply_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, V, V, V, V]),
         "smatrix_shard_apply_then_get_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, V, V, V, V, V]),
+        "smatrix_shard_transport": (C.c_char_p, [V]),
+        "smatrix_shard_get_placement": (C.c_int, [V, V, V, V, C.c_uint32, V]),
+        "smatrix_shard_route_dev": (V, [V, C.c_int, C.c_size_t, V, V, V, C.c_int, V]),
+        "smatrix_shard_apply_routed": (C.c_int, [V, V, C.c_int, V]),
+        "smatrix_shard_finish": (C.c_int, [V, V, V, V]),
+        "smatrix_shard_wait": (C.c_int, [V, V, V]),
+        "smatrix_shard_rowlen_dev": (C.c_int, [V, C.c_size_t, V, V, V]),
+        "smatrix_shard_getrow_dev": (C.c_int, [V, C.c_size_t, V, V, V, V, V]),
         # include/smx_probe.h
         "smx_probe_random_dev": (C.c_int, [V, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, V, V]),
         # include/smx_stream.h

@@ -577,9 +577,10 @@ class _null_ctx:
 
 class NativeShardedMatrix:
     """The router that lives in the C library (include/smatrix_shard.h, csrc/smx_shard.inc): the library partitions,
-    exchanges counts / records / results with grouped ncclSend/ncclRecv over RCCL and applies -- Python only hands
-    the 128-byte RCCL id from rank 0 to the other ranks (here through torch.distributed when it is initialised;
-    any launcher can do that) and passes device pointers.  Every call is collective."""
+    exchanges counts / records / results (RCCL, or the shared-memory test transport: SMATRIX_SHARD_TRANSPORT=shm),
+    plans and persists the placement and applies -- Python only hands the 128-byte id from rank 0 to the other ranks
+    (here through torch.distributed when it is initialised; any launcher can do that) and passes device pointers.
+    Every call is collective."""
 
     def __init__(self, filename=None, rank=None, world=None, unique_id=None):
         self._lib = _lib.load()
@@ -601,51 +602,63 @@ class NativeShardedMatrix:
         if not self._h:
             raise ValueError("smatrix_shard_open() failed")
         self.local = _BorrowedMatrix(self._lib, self._lib.smatrix_shard_local(self._h))
-        self._placed = False
-        self.placement = Placement(world)
 
-    def _plan_from_first_batch(self, x, hot_rows=256):
-        """COLLECTIVE, once: with several ranks and an EMPTY matrix the first write batch doubles as a sample -- every rank's
-        most frequent row ids are gathered and plan_placement() (the same planner ShardedMatrix uses) gives the hot rows to
-        shards one by one and the tail hash ranges of unequal width; the tables go to the library
-        (smatrix_shard_set_placement).  Under Zipf(1.1) equal ranges leave the hottest row's owner with 1.9x the mean load."""
-        if self._placed or self.world == 1 or not dist.is_initialized():
-            self._placed = True
-            return
-        self._placed = True
-        rows = [None] * self.world
-        dist.all_gather_object(rows, int(self.local.stats()["rows"]))
-        if sum(rows) or os.environ.get("SMATRIX_SHARD_PLACE", "1") == "0":
-            return                                       # rows exist already: they stay where equal ranges put them
-        mine = {}
-        if x.numel():
-            ux, cnt = torch.unique(x, return_counts=True)
-            top = torch.topk(cnt, min(hot_rows, ux.numel())).indices
-            mine = {int(a) & 0xFFFFFFFF: int(c) for a, c in zip(ux[top].tolist(), cnt[top].tolist())}
-        parts = [None] * self.world
-        dist.all_gather_object(parts, (mine, int(x.numel())))
-        counts, total = {}, 0
-        for part, n in parts:
-            total += n
-            for a, c in part.items():
-                counts[a] = counts.get(a, 0) + c
-        self.placement = plan_placement(counts, total, self.world, hot_rows)
-        self.set_placement(self.placement)
+    @staticmethod
+    def _ok(rc, what):
+        if rc:
+            raise RuntimeError("%s failed (%d)" % (what, rc))
+
+    @property
+    def transport(self):
+        return self._lib.smatrix_shard_transport(self._h).decode()
+
+    @property
+    def placement(self):
+        """the placement in force (planned by the library from the first write batch, loaded from <file>.placement, or set)"""
+        cuts = (C.c_uint32 * 64)()
+        pairs = (C.c_uint32 * 2048)()
+        nc, nr = C.c_uint32(0), C.c_uint32(0)
+        self._lib.smatrix_shard_get_placement(self._h, cuts, C.byref(nc), pairs, 1024, C.byref(nr))
+        return Placement(self.world, [int(cuts[i]) for i in range(nc.value)] if nc.value else None,
+                         {int(pairs[2 * i]): int(pairs[2 * i + 1]) for i in range(min(nr.value, 1024))})
 
     def apply_dev(self, op, x, y, v, out, stream=None):
-        if op != OP_GET:
-            self._plan_from_first_batch(x)
-        n = x.numel()
-        self._lib.smatrix_shard_apply_dev(self._h, op, n, x.data_ptr(), y.data_ptr(),
-                                          v.data_ptr() if v is not None else None, out.data_ptr(), stream)
+        self._ok(self._lib.smatrix_shard_apply_dev(self._h, op, x.numel(), x.data_ptr(), y.data_ptr(),
+                                                   v.data_ptr() if v is not None else None, out.data_ptr(), stream), "smatrix_shard_apply_dev")
 
     def apply_then_get_dev(self, op, x, y, v, out, out_get, stream=None):
-        self._plan_from_first_batch(x)
-        self._lib.smatrix_shard_apply_then_get_dev(self._h, op, x.numel(), x.data_ptr(), y.data_ptr(), v.data_ptr(),
-                                                   out.data_ptr(), out_get.data_ptr(), stream)
+        self._ok(self._lib.smatrix_shard_apply_then_get_dev(self._h, op, x.numel(), x.data_ptr(), y.data_ptr(), v.data_ptr(),
+                                                            out.data_ptr(), out_get.data_ptr(), stream), "smatrix_shard_apply_then_get_dev")
+
+    # split phases (include/smatrix_shard.h): h = route(...); apply_routed(h); finish(h, out[, out_get]); wait(h)
+    def route(self, op, x, y, v=None, inputs_ready=False, stream=None):
+        h = self._lib.smatrix_shard_route_dev(self._h, op, x.numel(), x.data_ptr(), y.data_ptr(),
+                                              v.data_ptr() if v is not None else None, int(inputs_ready), stream)
+        if not h:
+            raise RuntimeError("smatrix_shard_route_dev failed")
+        return (h, (x, y, v))                       # (the arrays must stay alive until the batch has been routed)
+
+    def apply_routed(self, h, then_get=False, stream=None):
+        self._ok(self._lib.smatrix_shard_apply_routed(self._h, h[0], int(then_get), stream), "smatrix_shard_apply_routed")
+
+    def finish(self, h, out, out_get=None):
+        self._ok(self._lib.smatrix_shard_finish(self._h, h[0], out.data_ptr(), out_get.data_ptr() if out_get is not None else None),
+                 "smatrix_shard_finish")
+
+    def wait(self, h, stream=None):
+        self._ok(self._lib.smatrix_shard_wait(self._h, h[0], stream), "smatrix_shard_wait")
+
+    def rowlen_dev(self, xs, out, stream=None):
+        self._ok(self._lib.smatrix_shard_rowlen_dev(self._h, xs.numel(), xs.data_ptr(), out.data_ptr(), stream), "smatrix_shard_rowlen_dev")
+        return out
+
+    def getrow_dev(self, xs, offsets, pairs, counts, stream=None):
+        """offsets int64 [n+1], pairs int32 [total, 2], counts int32 [n] (as SparseMatrix.getrow_batch_dev)"""
+        self._ok(self._lib.smatrix_shard_getrow_dev(self._h, xs.numel(), xs.data_ptr(), offsets.data_ptr(), pairs.data_ptr(),
+                                                    counts.data_ptr(), stream), "smatrix_shard_getrow_dev")
 
     def set_placement(self, placement):
-        """a Placement (plan_placement) -> the library's device tables; identical on every rank"""
+        """a Placement chosen by the caller -> the library's device tables; identical on every rank"""
         import numpy as np
         cuts = np.array(placement.cuts, dtype=np.uint32) if placement.cuts is not None else None
         slots, table = 0, None
