@@ -731,7 +731,8 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.single_device:
         local = 0
-        os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"
+        os.environ["SMATRIX_SHARD_HOST_STAGED"] = "1"        # the Python router: payload staged through the host (gloo)
+        os.environ["SMATRIX_SHARD_TRANSPORT"] = "shm"        # the C router: its shared-memory test transport
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.config in (3, 5):
@@ -851,9 +852,21 @@ def main():
             m.wait(h)
         lagging[:] = [h_i, h_g]
 
+    def step_c_router(s):
+        # the C library's router, split phases (include/smatrix_shard.h): the records of step s+1 are partitioned and
+        # exchanged by the library's communication thread while this thread drives the op kernels of step s
+        if args.no_overlap:
+            return m.apply_then_get_dev(OP_INCR, xs[s], ys[s], ones, out_i, out_g, stream)
+        h = pending.pop(s, None) or m.route(OP_INCR, xs[s], ys[s], ones, True, stream)
+        if s + 1 < total_steps and s + 1 != args.warmup:           # never across the timing fence
+            pending[s + 1] = m.route(OP_INCR, xs[s + 1], ys[s + 1], ones, True, stream)
+        m.apply_routed(h, True, stream)
+        m.finish(h, out_i, out_g)
+        m.wait(h, stream)
+
     def step(s):
         if args.c_router and sharded:
-            return m.apply_then_get_dev(OP_INCR, xs[s], ys[s], ones, out_i, out_g, stream)
+            return step_c_router(s)
         if comm is not None:
             return step_threaded(s)
         if sharded and not args.no_overlap:
@@ -904,7 +917,10 @@ def main():
         loads = [None] * world
         dist.all_gather_object(loads, int(m.exchanged_ops))
         mean = max(sum(loads) / world, 1)
-        shard_info = {"router": "C library (RCCL send/recv groups)", "rows_placed_by_load": len(m.placement.place),
+        shard_info = {"router": "C library (transport: %s; split phases on its communication thread; placement planned by the library)" % m.transport,
+                      "rows_placed_by_load": len(m.placement.place),
+                      "hash_range_widths": ([round((b - a) / 2.0 ** 32, 4) for a, b in zip([0] + m.placement.cuts, m.placement.cuts + [1 << 32])]
+                                            if m.placement.cuts is not None else "equal"),
                       "ops_applied_over_mean": [round(v / mean, 3) for v in loads]} if args.c_router else {"rows_placed_by_load": len(m.placement.place),
                       "hash_range_widths": ([round((b - a) / 2.0 ** 32, 4) for a, b in
                                              zip([0] + m.placement.cuts, m.placement.cuts + [1 << 32])]

@@ -27,6 +27,10 @@ u = lambda a: a.cpu().numpy().view(np.uint32)
 
 sh = NativeShardedMatrix(fname, rank=rank, world=world, unique_id=ident if world > 1 else None)
 assert sh.transport == ("shm" if world > 1 else "self"), sh.transport
+if os.environ.get("SMX_SKEWED_CUTS") and phase == "build":
+    # a placement chosen by the caller: hash ranges of very unequal width (a tenth of the space for every shard but the last)
+    from libsmatrix_amd.sharded import Placement
+    sh.set_placement(Placement(world, [int((k + 1) * 0.1 * 2 ** 32) for k in range(world - 1)], {}))
 first = 0 if phase == "build" else 1000
 gen = Stream("zipf", 777 + rank, 30000, 1.1, 1)
 save = {}

@@ -963,26 +963,42 @@ def test_sharded_two_ranks_one_gpu():
     assert p.returncode == 0 and "SHARDED_2RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_bench_launch_contract_n_ranks(world):
-    """the driver's N>1 launch line (torch.distributed.run, RANK/LOCAL_RANK/WORLD_SIZE from the env, ONE JSON
-    line from rank 0) on the 1-GPU rig: all ranks on cuda:0, gloo, host-staged exchange.  At 8 ranks (the node
-    size of the scaling run) the planned placement must leave every shard within 10 % of the mean load --
-    equal hash ranges put 1.9x the mean on the owner of the hottest row."""
+@pytest.mark.parametrize("world,router", [(2, "python"), (8, "python"), (8, "c")])
+def test_bench_launch_contract_n_ranks(world, router):
+    """`python bench.py --gpus N ...` AS GIVEN (no torch.distributed.run in front): bench.py spawns its own N ranks as
+    child processes before it touches a GPU, rank 0 prints the ONE JSON line.  On the 1-GPU rig all ranks sit on cuda:0
+    (gloo for the process group; the payload staged through the host / the C router's shared-memory transport).  N > 1 is
+    config 4 (8M x 8M ids, one stream per rank).  At 8 ranks -- the node size of the scaling run -- the planned placement
+    must leave every shard within 10 % of the mean load; equal hash ranges put 1.9x the mean on the owner of the hottest
+    row.  router = "c": the same through the C library's own router (include/smatrix_shard.h)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29611 + world), os.path.join(root, "bench.py"),
-           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch-lg", "18" if world == 2 else "20",
-           "--backend", "gloo", "--single-device"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--batch-lg", "18" if world == 2 else "20", "--backend", "gloo", "--single-device"] + (["--c-router"] if router == "c" else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["n_gpus"] == world and res["steps"] == 3 and res["scaling"] == "weak" and res["sanity_all_gets_positive"]
     assert res["value"] > 0 and "roofline" in res
+    assert res["config"]["workload"].startswith("config-4") and res["config"]["ids_per_axis"] == 8000000
     pl = res["config"]["placement"]
     assert pl["rows_placed_by_load"] > 0 and len(pl["ops_applied_over_mean"]) == world
     if world == 8:
         assert max(pl["ops_applied_over_mean"]) < 1.10, pl
+
+
+def test_bench_launch_contract_torchrun():
+    """the driver's other launch line: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N (RANK /
+    LOCAL_RANK / WORLD_SIZE from the environment): no second fan-out, one JSON line"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-lg", "18",
+           "--backend", "gloo", "--single-device"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2

@@ -258,14 +258,28 @@ def test_native_router_n_ranks_on_one_gpu(oracle_mod, tmp_path, world):
     o.close()
 
 
-def test_shard_files_without_their_placement_are_refused(oracle_mod, tmp_path):
-    """rows written under a planned placement sit away from their equal-range owners: reopening the shard files WITHOUT
-    the .placement file must fail loudly instead of routing ops to the wrong shard (get -> 0, incr -> a forked row)"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_shard_files_without_their_placement(oracle_mod, tmp_path, world):
+    """rows written under a planned placement sit away from their equal-range owners.  Reopened WITHOUT the .placement
+    file, a handful of such rows (2 shards: the hot rows that were placed one by one and the few between the old and
+    the new cut) are found and kept where they are; thousands of them (4 shards under hash ranges of very unequal width,
+    set by the caller) mean the file of a placed matrix is missing, and the library must fail loudly instead of routing ops to the wrong shard
+    (get -> 0, incr -> a forked row)."""
     out = str(tmp_path)
+    o = oracle_mod.Oracle()
     env = {"SMX_OUT": out, "SMX_FILE": str(tmp_path / "m"), "SMX_STEPS": "2", "SMX_N": str(1 << 16)}
-    _run_ranks(2, dict(env, SMX_PHASE="build"))
-    for r in range(2):
+    if world == 4:
+        env["SMX_SKEWED_CUTS"] = "1"                        # (a planned placement of a Zipf stream keeps the ranges nearly equal)
+    _run_ranks(world, dict(env, SMX_PHASE="build"))
+    _check_phase(oracle_mod, o, out, world, "build", [])
+    for r in range(world):
         os.unlink(str(tmp_path / ("m.shard%d.smx.placement" % r)))
-    with pytest.raises(AssertionError) as e:
-        _run_ranks(2, dict(env, SMX_PHASE="reopen"), timeout=300)
-    assert "placement" in str(e.value)
+    if world == 2:
+        _run_ranks(world, dict(env, SMX_PHASE="reopen"), timeout=300)
+        d = _check_phase(oracle_mod, o, out, world, "reopen", [])
+        assert all(0 < int(q["placed_rows"]) <= 512 and q["cuts"].size == 0 for q in d)     # equal ranges + the rows found away from them
+    else:
+        with pytest.raises(AssertionError) as e:
+            _run_ranks(world, dict(env, SMX_PHASE="reopen"), timeout=300)
+        assert "placement" in str(e.value)
+    o.close()
