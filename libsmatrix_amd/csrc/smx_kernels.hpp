@@ -2202,37 +2202,46 @@ __device__ inline uint32_t getrow_cap(const uint64_t* offsets, uint32_t r) {
   return c > 0xffffffffull ? 0xffffffffu : (uint32_t)c;
 }
 
+template <int AHEAD = 2, bool XCD = true, int DBG = 0>     // DBG: measurement variants only (1: no pair stores, 2: no cell loads)
 __global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, uint8_t* arena,
                                                 uint32_t n, const uint32_t* __restrict__ xs,
                                                 const uint64_t* __restrict__ offsets,
                                                 uint64_t* __restrict__ ret,
                                                 uint32_t* __restrict__ counts, uint32_t* big) {
-  uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // Workgroups are dealt to the 8 XCDs round robin (MI355X_MICROARCH.md), each XCD with its own L2.  Consecutive rows of
+  // the request write consecutive output ranges whose ends share cache lines: numbered naively, the four rows of
+  // workgroup b and those of b + 1 meet in a line that two L2s each hold half of, and both halves reach memory as
+  // partial-line writes.  So workgroups are RENUMBERED: XCD x takes the virtual workgroups [x * G/8, (x+1) * G/8), a
+  // contiguous range of rows per sweep, and neighbours' partial lines merge in its L2.
+  const uint32_t G = gridDim.x;
+  const uint32_t vb = XCD && (G & 7u) == 0 ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  uint32_t wave = (vb * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  uint32_t nwaves = (G * blockDim.x) >> 6;
   const uint64_t lt = (1ull << lane) - 1;
   // A row is a chain of dependent accesses (id -> directory slot -> cells -> pairs out) and a CF-shaped
   // row is only 1-2 KiB: a wave that walks one row at a time spends its life waiting.  Two rows are in
-  // flight per wave instead: both directory slots are requested together, then both rows' first 128 cells.
+  // flight per wave instead: both directory slots are requested together, then ALL cells of both rows up to 512 per
+  // row (four 1 KiB steps each: every load of a CF row is in flight before the first one is consumed -- round 2 fetched
+  // the second KiB of a 256-cell row only after the first had been compacted).
   struct Row {
     bool live, scan;
     uint32_t r, size, cap, written;
     uint64_t off;
     const uint4* cells;
-    uint4 c;
   };
-  auto step = [&](Row& w, uint32_t p0) {             // compacts the 128 cells held in w.c (slot order)
-    const bool ne0 = (w.c.x | w.c.y) != 0, ne1 = (w.c.z | w.c.w) != 0;
+  auto step = [&](Row& w, const uint4 c) {           // compacts the 128 cells held in c (slot order)
+    const bool ne0 = (c.x | c.y) != 0, ne1 = (c.z | c.w) != 0;
     const uint64_t m0 = __ballot(ne0), m1 = __ballot(ne1);
     uint32_t rank = w.written + (uint32_t)__popcll(m0 & lt) + (uint32_t)__popcll(m1 & lt);
-    if (ne0 && rank < w.cap) ret[w.off + rank] = pack_cell(w.c.x, w.c.y);
+    if (DBG != 1 && ne0 && rank < w.cap) ret[w.off + rank] = pack_cell(c.x, c.y);
     rank += ne0;
-    if (ne1 && rank < w.cap) ret[w.off + rank] = pack_cell(w.c.z, w.c.w);
+    if (DBG != 1 && ne1 && rank < w.cap) ret[w.off + rank] = pack_cell(c.z, c.w);
     w.written += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
-    (void)p0;
   };
   auto fetch = [&](const Row& w, uint32_t p0) -> uint4 {
     const uint32_t p = p0 + 2 * lane;
+    if (DBG == 2) return p < w.size && (p & 3u) ? make_uint4(p, 1, 0, 0) : make_uint4(0, 0, 0, 0);
     return p < w.size ? w.cells[p >> 1] : make_uint4(0, 0, 0, 0);
   };
   for (uint32_t r0 = wave; r0 < n; r0 += 2 * nwaves) {
@@ -2244,6 +2253,7 @@ __global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, ui
       w[k].live = w[k].r < n;
       w[k].scan = false;
       w[k].written = 0;
+      w[k].size = 0;
       X[k] = w[k].live ? xs[w[k].r] : 0u;
       h[k] = fmix32(X[k]) & dmask;
     }
@@ -2259,21 +2269,52 @@ __global__ __launch_bounds__(256) void k_getrow(DirSlot* dir, uint32_t dmask, ui
       if (w[k].size > GETROW_WAVE_MAX) {
         if (lane == 0) big[1 + atomicAdd(&big[0], 1u)] = w[k].r;
         w[k].live = false;                                                               // k_getrow_big writes its count
+        w[k].size = 0;
         continue;
       }
-      w[k].off = offsets[w[k].r];
-      w[k].cap = getrow_cap(offsets, w[k].r);
       w[k].cells = reinterpret_cast<const uint4*>(row_cells(arena, s[k].z));
       w[k].scan = true;
     }
-    for (int k = 0; k < 2; k++)
-      if (w[k].scan) w[k].c = fetch(w[k], 0);                                            // both in flight
+    // FAST PATH (wave-uniform): both rows are there and have at most 256 cells -- the CF shape.  Straight-line code: four
+    // 1 KiB loads, the four offsets, then compaction and stores, nothing data-dependent between the loads' issue and
+    // their first use.  (Round 3: tools/probe/row_gather.cpp does exactly this in 7.8 ms for 13 M rows on a box where
+    // the general loop below takes 10.0.)
+    if (AHEAD >= 2 && w[0].scan && w[1].scan && w[0].size <= 256 && w[1].size <= 256) {
+      uint4 c[2][2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        c[k][0] = fetch(w[k], 0);
+        c[k][1] = fetch(w[k], 128);
+      }
+      uint64_t o0[2], o1[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) { o0[k] = offsets[w[k].r]; o1[k] = offsets[w[k].r + 1]; }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        w[k].off = o0[k];
+        const uint64_t cc = o1[k] - o0[k];
+        w[k].cap = cc > 0xffffffffull ? 0xffffffffu : (uint32_t)cc;
+        step(w[k], c[k][0]);
+        step(w[k], c[k][1]);
+        if (lane == 0) counts[w[k].r] = min(w[k].written, w[k].cap);
+      }
+      continue;
+    }
     for (int k = 0; k < 2; k++) {
       if (w[k].scan) {
-        step(w[k], 0);
-        for (uint32_t p0 = 128; p0 < w[k].size && w[k].written < w[k].cap; p0 += 128) {
-          w[k].c = fetch(w[k], p0);
-          step(w[k], p0);
+        w[k].off = offsets[w[k].r];
+        w[k].cap = getrow_cap(offsets, w[k].r);
+      }
+    }
+    uint4 c0[2];
+    for (int k = 0; k < 2; k++) c0[k] = w[k].scan ? fetch(w[k], 0) : make_uint4(0, 0, 0, 0);   // both in flight
+    for (int k = 0; k < 2; k++) {
+      if (w[k].scan) {
+        step(w[k], c0[k]);
+        for (uint32_t p0 = 128; p0 < w[k].size && w[k].written < w[k].cap; p0 += 256) {
+          const uint4 a = fetch(w[k], p0), b2 = fetch(w[k], p0 + 128);                  // two steps in flight
+          step(w[k], a);
+          if (p0 + 128 < w[k].size && w[k].written < w[k].cap) step(w[k], b2);
         }
         if (w[k].written > w[k].cap) w[k].written = w[k].cap;
       }
@@ -2716,8 +2757,22 @@ __global__ __launch_bounds__(256) void k_part_count(uint32_t n, const uint32_t* 
   if (threadIdx.x < MAX_SHARDS) h[threadIdx.x] = 0;
   place_stage(l_place, place, place_slots, cuts, nshards);
   __syncthreads();
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    atomicAdd(&h[owner_of(xs[i], nshards, l_place, place_slots, cuts != nullptr)], 1u);
+  // one LDS atomic per distinct owner and WAVE (ballots): with a handful of shards every lane of a wave names one of a
+  // few counters, and 64 same-address LDS atomics serialise (round 3, 2^24 ops, one shard: 63 us before)
+  const uint32_t lane = __lane_id();
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {        // block-uniform
+    const uint32_t i = i0 + threadIdx.x;
+    const bool live = i < n;
+    const uint32_t o = live ? owner_of(xs[i], nshards, l_place, place_slots, cuts != nullptr) : 0u;
+    uint64_t todo = __ballot(live);
+    while (todo) {
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+      const uint32_t o0 = (uint32_t)__shfl((int)o, (int)leader);
+      const uint64_t m = __ballot(live && o == o0);
+      if (lane == leader) atomicAdd(&h[o0], (uint32_t)__popcll(m));
+      todo &= ~m;
+    }
+  }
   __syncthreads();
   if (threadIdx.x < nshards && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
@@ -2754,10 +2809,22 @@ __global__ __launch_bounds__(256) void k_part_scatter(
   for (uint32_t k = 0; k < PART_OPT; k++) {
     uint32_t i = tile0 + k * 256 + threadIdx.x;
     sh[k] = ~0u;
-    if (i < n) {
+    const bool live = i < n;
+    if (live) {
       X[k] = xs[i];
       sh[k] = owner_of(X[k], nshards, l_place, place_slots, cuts != nullptr);
-      rk[k] = atomicAdd(&cnt[sh[k]], 1u);
+    }
+    // ranks inside the tile: one LDS atomic per distinct owner and wave, lanes rank themselves by ballot
+    uint64_t todo = __ballot(live);
+    while (todo) {
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+      const uint32_t o0 = (uint32_t)__shfl((int)sh[k], (int)leader);
+      const uint64_t m = __ballot(live && sh[k] == o0);
+      uint32_t base0 = 0;
+      if (__lane_id() == leader) base0 = atomicAdd(&cnt[o0], (uint32_t)__popcll(m));
+      base0 = (uint32_t)__shfl((int)base0, (int)leader);
+      if (live && sh[k] == o0) rk[k] = base0 + (uint32_t)__popcll(m & ((1ull << __lane_id()) - 1ull));
+      todo &= ~m;
     }
   }
   __syncthreads();
@@ -2812,6 +2879,12 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t n, const uint32_t* __re
                                                 uint32_t* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = src[perm[i]];
+}
+
+__global__ __launch_bounds__(256) void k_gather2(uint32_t n, const uint32_t* __restrict__ src, const uint32_t* __restrict__ src2,
+                                                 const uint32_t* __restrict__ perm, uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const uint32_t p = perm[i]; out[i] = src[p]; out2[i] = src2[p]; }
 }
 
 // ---- random-access probes (include/smx_probe.h) ------------------------------------------------

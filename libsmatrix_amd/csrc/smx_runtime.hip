@@ -1403,8 +1403,18 @@ void launch_getrow(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* x, cons
   m->big.need((size_t)n + 1);
   HIP_OK(hipMemsetAsync(m->big.p, 0, 4, s));
   uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
-  hipLaunchKernelGGL(k_getrow, dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x,
-                     off, ret, counts, m->big.p);
+  static const int variant = getenv("SMATRIX_GETROW_VARIANT") ? atoi(getenv("SMATRIX_GETROW_VARIANT")) : 0;   // (tools/probe/getrow_variants.py)
+#define GR(A, X, D) hipLaunchKernelGGL((k_getrow<A, X, D>), dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, off, ret, counts, m->big.p)
+  switch (variant) {
+    case 1: GR(1, false, 0); break;      // round 2's shape: one step ahead, workgroups as numbered
+    case 2: GR(1, true, 0); break;
+    case 3: GR(4, true, 0); break;
+    case 4: GR(2, false, 0); break;
+    case 5: GR(2, true, 1); break;       // no pair stores
+    case 6: GR(2, true, 2); break;       // no cell loads
+    default: GR(2, true, 0); break;
+  }
+#undef GR
   // rows of more than 8192 cells were only noted down: a workgroup per row -- per segment of a giant row -- (with
   // none noted the three launches are a few idle workgroups)
   const uint64_t most = (uint64_t)n + m->arena.mapped / 8 / GETROW_SEG;
@@ -1653,7 +1663,7 @@ uint32_t smatrix_getrow(smatrix_t* self, uint32_t x, uint32_t* ret, size_t ret_l
   if (want <= SCALAR_ROW_PAIRS) {
     h[0] = 0; h[1] = x; h[2] = 0; h[3] = 0;
     offs[0] = 0; offs[1] = want;
-    hipLaunchKernelGGL(k_getrow, dim3(1), dim3(64), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, 1u, h + 1,
+    hipLaunchKernelGGL((k_getrow<2, false, 0>), dim3(1), dim3(64), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, 1u, h + 1,
                        offs, pairs, h, h + 2);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(s));
