@@ -597,28 +597,70 @@ def op_kinds_leg(torch, dev, m, x, y, B, stream):
     return r
 
 
-def sustained_leg(torch, dev, m, gen, first_step, B, seconds, stream):
+def sustained_leg(torch, dev, m, gen, first_step, B, seconds, stream, group=16):
+    """the SAME step on the continuing stream in back-to-back timed groups of `group` steps (inputs generated between
+    the groups).  Per group: ms per step and what the table did meanwhile (rounds, rows grown, arena mapped) -- VERDICT r2
+    asked where a 3.0 ms group comes from when the headline step is 2.4 ms."""
     from libsmatrix_amd import OP_GET, OP_INCR
-    group = 32                                                # batches generated per untimed refill (4 GB of ids)
     xs = torch.empty((group, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
     ones = torch.ones(B, dtype=torch.int32, device=dev)
     o1 = torch.empty(B, dtype=torch.int32, device=dev); o2 = torch.empty_like(o1)
     busy, steps, s = 0.0, 0, first_step
+    groups = []
+    keys = ("rounds", "rows_grown", "deferred_ops", "arena_mapped", "spec_chains", "spec_refused", "dir_grown")
     while busy < seconds and steps < 4096:
         for k in range(group):
             gen.fill_device((s + k) * B, B, xs[k].data_ptr(), ys[k].data_ptr(), stream)
+        st0 = m.stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(group):
             m.apply_batch_dev(OP_INCR, B, xs[k].data_ptr(), ys[k].data_ptr(), ones.data_ptr(), o1.data_ptr(), stream)
             m.apply_batch_dev(OP_GET, B, xs[k].data_ptr(), ys[k].data_ptr(), None, o2.data_ptr(), stream)
         torch.cuda.synchronize()
-        busy += time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        st1 = m.stats()
+        busy += dt
+        groups.append(dict({k: int(st1[k]) - int(st0[k]) for k in keys}, first_step=s, ms_per_step=round(dt / group * 1e3, 4)))
         steps += group; s += group
     st = m.stats()
+    per = sorted(g["ms_per_step"] for g in groups)
     return {"steps": steps, "timed_s": busy, "ms_per_step": busy / steps * 1e3, "Mops_per_s": 2 * B * steps / busy / 1e6,
-            "stream_ops_at_end": s * B, "rows": int(st["rows"]),
-            "note": "continues the config-2 stream past 4e8 ops in timed groups of %d steps (inputs generated between groups)" % group}
+            "ms_per_step_median_group": per[len(per) // 2], "ms_per_step_best_group": per[0], "ms_per_step_worst_group": per[-1],
+            "groups": groups, "stream_ops_at_end": s * B, "rows": int(st["rows"]), "next_step": s,
+            "note": "continues the config-2 stream past 4e8 ops in timed groups of %d steps (inputs generated between groups); a group in "
+                    "which one of the giant rows doubles (rows_grown, rounds) carries that row's whole rehash" % group}
+
+
+def batch_size_leg(torch, dev, lg, stream):
+    """the config-2 stream in batches of 2^lg ops (batches of 2^24 - 2^26), fresh matrix, same 4e8-op stream:
+    the per-batch fixed cost (the rounds after round 0: ~0.3 ms of small launches) is shared by four times the ops"""
+    from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
+    B = 1 << lg
+    nb = max((400000000 + B - 1) // B, 3)
+    gen = Stream("zipf", SEED, N_IDS, ZIPF_S, 1)
+    m = SparseMatrix()
+    m.reserve(8 << 30)
+    xs = torch.empty((nb, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
+    for k in range(nb):
+        gen.fill_device(k * B, B, xs[k].data_ptr(), ys[k].data_ptr(), stream)
+    ones = torch.ones(B, dtype=torch.int32, device=dev)
+    o1 = torch.empty(B, dtype=torch.int32, device=dev); o2 = torch.empty_like(o1)
+    warm = 1
+    for k in range(nb):
+        if k == warm:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.apply_batch_dev(OP_INCR, B, xs[k].data_ptr(), ys[k].data_ptr(), ones.data_ptr(), o1.data_ptr(), stream)
+        m.apply_batch_dev(OP_GET, B, xs[k].data_ptr(), ys[k].data_ptr(), None, o2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    ok = bool((o2 >= 1).all().item()) and int(st["rows"]) <= N_IDS
+    m.close(); gen.close()
+    n = nb - warm
+    return {"batch_lg": lg, "steps": n, "ms_per_step": dt / n * 1e3, "ms_per_2^24_ops_step": dt / n * 1e3 / (B >> 24),
+            "Mops_per_s": 2 * B * n / dt / 1e6, "rounds": int(st["rounds"]), "sanity": ok,
+            "note": "NOT `value` (that stays at 2^24-op batches, comparable across rounds): the same stream in %d batches of 2^%d ops" % (nb, lg)}
 
 
 def dense_ids_leg(torch, dev, B, stream, steps=24):
@@ -945,15 +987,20 @@ def main():
     extras = {}
     if not sharded and not args.no_extras and args.batch_lg == BATCH_LG:
         # (1) the reference-held checksums of this very stream, on a fresh matrix (outside the timed region)
-        extras["reference_checksums"] = verify_config2(torch, dev, xs_all, ys_all, B, ring)
         # (2) sustained leg: the SAME step on the continuing stream (fresh batches, table keeps growing) for >= 1 s of
-        #     back-to-back steps, so that the run holds a timed region far longer than any sampling period
+        #     back-to-back steps, so that the run holds a timed region far longer than any sampling period -- once right
+        #     behind the timed steps, once more after the checksum replay has opened, filled and closed a second matrix
         extras["sustained"] = guarded(sustained_leg, torch, dev, m, gen, total_steps, B, args.sustain_s, stream)
+        extras["reference_checksums"] = verify_config2(torch, dev, xs_all, ys_all, B, ring)
+        nxt = extras["sustained"].get("next_step", total_steps) if isinstance(extras["sustained"], dict) else total_steps
+        extras["sustained_after_checksum_replay"] = guarded(sustained_leg, torch, dev, m, gen, nxt, B, 0.5, stream)
         # (3) dense ids (id = Zipf rank, no scramble): the reference's identity-hash tables cluster here
         #     (displacement 10^3-10^4); secondary metric
         extras["dense_ids"] = guarded(dense_ids_leg, torch, dev, B, stream)
         # (4) the four op kinds on the finished table
         extras["op_kinds"] = guarded(op_kinds_leg, torch, dev, m, xs[total_steps - 1], ys[total_steps - 1], B, stream)
+        # (5) the same stream in 2^26-op batches (the upper end of SURVEY 8d's range): per-batch fixed costs shared by 4x the ops
+        extras["batch_2_26"] = guarded(batch_size_leg, torch, dev, 26, stream)
 
     total_ops = 2 * B * args.steps * world
     res = {
@@ -1011,7 +1058,7 @@ def main():
         if steady:
             res["steady_state_all_hits"] = steady
         res["table"] = {k: st[k] for k in ("rows", "dir_slots", "arena_units", "arena_mapped", "batches",
-                                           "rounds", "deferred_ops", "rows_grown", "dir_grown")}
+                                           "rounds", "deferred_ops", "rows_grown", "dir_grown", "spec_chains", "spec_refused", "bulk_rounds")}
         if world == 1 and not sharded and not args.no_extras:
             del xs_all, ys_all
             res["config3_getrow"] = guarded(run_config3, torch, dev)

@@ -283,3 +283,51 @@ def test_shard_files_without_their_placement(oracle_mod, tmp_path, world):
             _run_ranks(world, dict(env, SMX_PHASE="reopen"), timeout=300)
         assert "placement" in str(e.value)
     o.close()
+
+
+def test_batch_of_more_than_2_to_31_ops():
+    """maximum sizes: ONE incr batch of 2^31 + 2^27 ops into an empty matrix, then ONE get batch of the same length.
+    Op numbers, deferred-op lists and list positions are 32-bit throughout; the bulk path keeps a flag in bit 31 of a
+    list position and must step aside (commit 4ae7d9c, never executed until now).  Every key is distinct (row = i mod R,
+    column = 1 + i div R with R = n / 1024): every incr must return 1, every get 1, every row must hold exactly 1024
+    columns in a 2048-cell table (the smallest 16 * 2^k with 1024 <= 8 * 2^k + 1, src/smatrix.c:346), n cells in all."""
+    import torch
+    import libsmatrix_amd
+    from libsmatrix_amd import SparseMatrix, OP_GET, OP_INCR
+    dev = torch.device("cuda", 0)
+    libsmatrix_amd._lib.load().smatrix_release_cached_memory()
+    free, total = torch.cuda.mem_get_info(dev)
+    if free < 140e9:
+        pytest.skip("needs ~110 GB of free HBM")
+    n = (1 << 31) + (1 << 27)
+    R = n // 1024
+    x = torch.empty(n, dtype=torch.int32, device=dev); y = torch.empty_like(x)
+    step = 1 << 28
+    for a in range(0, n, step):
+        i = torch.arange(a, min(n, a + step), dtype=torch.int64, device=dev)
+        x[a:a + i.numel()] = (i % R).to(torch.int32)
+        y[a:a + i.numel()] = (i // R + 1).to(torch.int32)
+        del i
+    ones = torch.ones(n, dtype=torch.int32, device=dev)
+    out = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    m = SparseMatrix()
+    m.apply_batch_dev(OP_INCR, n, x.data_ptr(), y.data_ptr(), ones.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = m.stats()
+    assert st["rows"] == R and st["bulk_ops"] == 0, st                     # 2^31+ pending ops: not for the bulk path
+    assert int(out.min().item()) == 1 and int(out.max().item()) == 1
+    out.zero_()
+    m.apply_batch_dev(OP_GET, n, x.data_ptr(), y.data_ptr(), None, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert int(out.min().item()) == 1 and int(out.max().item()) == 1
+    del ones, out, y
+    rows = torch.arange(0, R, dtype=torch.int32, device=dev)
+    lens = torch.empty(R, dtype=torch.int32, device=dev)
+    m.rowlen_batch_dev(R, rows.data_ptr(), lens.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert int(lens.min().item()) == 1024 and int(lens.max().item()) == 1024
+    assert m.row_info(5) == (2048, 1024) and m.row_info(R - 1) == (2048, 1024) and m.row_info(R) is None
+    m.close()
+    del x, rows, lens
+    libsmatrix_amd._lib.load().smatrix_release_cached_memory()
