@@ -442,7 +442,10 @@ __device__ __forceinline__ void apply_body(
   // {x,y} / {x,y,v} records with xs = rec, ys = rec + 1, vs = rec + 2: what the sharded exchange delivers)
   // n == 0xFFFFFFFF: the list's length is on the device (ctl->n_prev: the host has not read the previous round back)
   if (n == 0xFFFFFFFFu) n = aload(&ctl->n_prev);
-  for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
+  // (64-bit trip counter: with n > 2^31 ops and a grid that covers them all, t0 + the grid's size wraps around in 32 bits
+  //  and the ops at the front would be applied a SECOND time -- round 3, found by the 2^31 + 2^27-op batch test)
+  for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
+    const uint32_t t0 = (uint32_t)t064;
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
     uint32_t j = 0, r = 0, Y = 0, V = 0;
@@ -840,8 +843,9 @@ __device__ __forceinline__ void prep_body(
   __shared__ uint32_t l_k[8], l_kb[8];             // growth tasks filed by this block: total, by kind; list bases
   __shared__ unsigned long long l_units;
   const uint32_t n = aload(&ctl->n_defer);
-  const uint32_t stride = g.nb * blockDim.x;
-  for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += stride) {             // block-uniform trip count
+  const uint64_t stride = (uint64_t)g.nb * blockDim.x;
+  for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n; t064 += stride) {             // block-uniform trip count (64-bit: no wrap near 2^32)
+    const uint32_t t0 = (uint32_t)t064;
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
     uint32_t X = 0, Y = 0;
@@ -2760,8 +2764,8 @@ __global__ __launch_bounds__(256) void k_part_count(uint32_t n, const uint32_t* 
   // one LDS atomic per distinct owner and WAVE (ballots): with a handful of shards every lane of a wave names one of a
   // few counters, and 64 same-address LDS atomics serialise (round 3, 2^24 ops, one shard: 63 us before)
   const uint32_t lane = __lane_id();
-  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {        // block-uniform
-    const uint32_t i = i0 + threadIdx.x;
+  for (uint64_t i064 = (uint64_t)blockIdx.x * blockDim.x; i064 < n; i064 += (uint64_t)gridDim.x * blockDim.x) {        // block-uniform
+    const uint32_t i = (uint32_t)i064 + threadIdx.x;
     const bool live = i < n;
     const uint32_t o = live ? owner_of(xs[i], nshards, l_place, place_slots, cuts != nullptr) : 0u;
     uint64_t todo = __ballot(live);

@@ -405,6 +405,7 @@ struct Matrix {
   uint32_t agg_min_retry = 1u << 20;
   bool profile = false;
   bool trace_rounds = false;            // SMATRIX_TRACE_ROUNDS=1: one stderr line per round
+  bool trace_sync = false;              // SMATRIX_TRACE_ROUNDS=2: ... and a stream sync + a line after every launch (DBG_STEP)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   struct TimedLaunch { hipEvent_t e0, e1; uint32_t n; };
   std::deque<TimedLaunch> get_pending;  // profiled get launches whose events have not been read yet (get_timing_resolve)
@@ -453,6 +454,18 @@ struct Matrix {
 };
 
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
+
+// SMATRIX_TRACE_ROUNDS=2: wait for the stream after every launch of a write batch and say which one it was -- the last line
+// before a GPU fault names the kernel
+#define DBG_STEP(m, s, what)                                                          \
+  do {                                                                                \
+    if ((m)->trace_sync) {                                                            \
+      fprintf(stderr, "[smatrix]     %s ...", what); fflush(stderr);                  \
+      HIP_OK(hipStreamSynchronize(s));                                                \
+      if ((m)->helper) HIP_OK(hipStreamSynchronize((m)->helper));                     \
+      fprintf(stderr, " done\n");                                                    \
+    }                                                                                 \
+  } while (0)
 
 void ctl_reset_round(Matrix* m, hipStream_t s) {
   HIP_OK(hipMemsetAsync(m->d_ctl, 0, CTL_ROUND_BYTES, s));     // the persistent part stays on the device
@@ -647,6 +660,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   hipLaunchKernelGGL(k_grow_plan, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, cap_units, m->fl, spec ? nt : 0xFFFFFFFFu,
                      spec ? (uint32_t)std::min<uint64_t>(m->map_old.cap, m->map_new.cap / 2) : 0xFFFFFFFFu);
+  DBG_STEP(m, s, "k_grow_plan");
   const uint32_t n_chunked = nk[GROW_CHUNKED];
   // the chunked passes of the large rows touch other rows than the in-LDS rehashes: they run on a helper stream beside
   // them, from the plan on (non-blocking stream + events: the caller's stream may be the legacy default stream, which a
@@ -663,6 +677,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   if (nk[2])
     hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), 16u << GROW_LG2, s,
                        m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base);
+  DBG_STEP(m, s, "k_grow_lds x3");
   const uint64_t oc_bound = (uint64_t)n_chunked + gu / 8, nc_bound = (uint64_t)n_chunked + gu / 4;
   hipStream_t sc = s;
   if (fork) {
@@ -679,6 +694,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   }
+  DBG_STEP(m, s, "chunked passes");
   if (fork) {
     HIP_OK(hipEventRecord(m->ev_join, sc));
     HIP_OK(hipStreamWaitEvent(s, m->ev_join, 0));
@@ -686,6 +702,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
   HIP_OK(hipGetLastError());
+  DBG_STEP(m, s, "k_grow_commit");
   if (m->trace_rounds && nt > 1000 && !spec) {      // who grows?  (cells moved, by log2 of the old row size)
     std::vector<GrowTask> ht(nt);
     HIP_OK(hipMemcpyAsync(ht.data(), m->tasks.p, (size_t)nt * sizeof(GrowTask), hipMemcpyDeviceToHost, s));
@@ -828,6 +845,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room) + (chained ? est_gu : 0), s);
     ctl_reset_round(m, s);
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
+    DBG_STEP(m, s, m->long_probes ? "op kernel (lane per op)" : "op kernel");
 #if defined(SMX_AGG_DBG) && SMX_AGG_DBG == 5
     // measurement build "inserts without tickets": rows overfill and their deferred ops never converge -- only the
     // round-0 launch is of interest, what it deferred is dropped
@@ -876,6 +894,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     };
     launch_prep(dl);
     HIP_OK(hipGetLastError());
+    DBG_STEP(m, s, "k_prep");
     uint32_t nd_chain0 = 0;
     if (chained) {
       // ---- the rest of the chain: growth for the rows round 0's prep flagged, the retry, its prep -- no read-back between
@@ -1203,7 +1222,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
-  if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) m->trace_rounds = *t == '1';
+  if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) { m->trace_rounds = *t == '1' || *t == '2'; m->trace_sync = *t == '2'; }
   const char* prof = getenv("SMATRIX_PROFILE");
   m->profile = prof && *prof == '1';
 
