@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void prep_body(
       __syncthreads();
       if (mk) {
         const uint32_t k = l_kb[0] + rk;
-        if (kind != GROW_CHUNKED) klist[kind * kcap + l_kb[1 + kind] + rkk] = k;
+        klist[kind * kcap + l_kb[1 + kind] + rkk] = k;       // (kind 3, the chunked rows: k_grow_map walks that list)
         tasks[k].dslot = h;
         tasks[k].old_lg = t_lg;
         tasks[k].old_base = t_base;
@@ -1709,14 +1709,16 @@ __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, ui
   grow_plan_body(SMX_VG, ctl, tasks, arena_cap_units, fl, task_budget, chunk_cap);
 }
 
-// chunk -> task maps, filled one wave per task
-__device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const GrowTask* tasks,
+// chunk -> task maps, filled one wave per CHUNKED task (prep lists them: a steady batch has ~50 of them among 60 000
+// tasks, and a wave per task of ALL kinds made this trivial pass 40 us of the growth round's critical path)
+__device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const GrowTask* tasks, const uint32_t* list,
                                               uint32_t* map_old, uint32_t* map_new) {
-  uint32_t n = aload(&ctl->n_tasks);
+  uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
   uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
   uint32_t nwaves = (g.nb * blockDim.x) >> 6;
-  for (uint32_t t = wave; t < n; t += nwaves) {
+  for (uint32_t li = wave; li < n; li += nwaves) {
+    const uint32_t t = list[li];
     const GrowTask k = tasks[t];
     if (grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE) continue;   // (a range whose task got no block is
     const uint32_t oc = 1u << (k.old_lg - 6), nc = 2u * oc;                          //  still mapped: the passes skip it by new_base)
@@ -1724,9 +1726,9 @@ __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const Gro
     for (uint32_t c = lane; c < nc; c += 64) map_new[k.chunk0_new + c] = t;
   }
 }
-__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks,
+__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks, const uint32_t* list,
                                                   uint32_t* map_old, uint32_t* map_new) {
-  grow_map_body(SMX_VG, ctl, tasks, map_old, map_new);
+  grow_map_body(SMX_VG, ctl, tasks, list, map_old, map_new);
 }
 
 // Rows whose old and new table fit in LDS are rebuilt there by one wave or one workgroup (the SCOPE).
@@ -2034,7 +2036,9 @@ __global__ void k_rebal(const Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uin
 // Between two op rounds that the HOST does not separate (speculative chain): what round 0 deferred becomes the length
 // of the list the next round reads, round 0's counters are kept for the host's statistics, and the per-round part of the
 // control block starts from zero again (what ctl_reset_round does from the host).  One lane.
-__global__ void k_round_advance(Ctl* ctl) {
+__global__ void k_round_advance(Ctl* ctl, const uint32_t* rebal, DirSlot* dir, uint8_t* arena) {
+  rebal_body(VGrid{0, 1}, ctl, rebal, dir, arena);     // (the handful of big rows whose quotas want re-partitioning: no launch of their own)
+  __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   ctl->n_prev = ctl->n_defer;
   ctl->spec_nd0 = ctl->n_defer;

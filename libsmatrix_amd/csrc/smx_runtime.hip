@@ -685,8 +685,8 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     sc = m->helper;
   }
   if (n_chunked) {
-    hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)nt * 64), 2048)),
-                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->map_new.p);
+    hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)n_chunked * 64), 2048)),
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p);
     hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
     hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
@@ -835,7 +835,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // at most one growth task / re-partition per row, and only rows named by a deferred op
     m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
     m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
-    m->klist.need(3 * (size_t)m->klist_cap);
+    m->klist.need(4 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
     uint32_t* dl = m->defer[round & 1].p;
     const bool chained = chain && round == 0;
@@ -903,8 +903,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       const uint64_t host_next = m->arena_next;
       grow_rows(m, s, est_nt, est_gu, est_nk, true);
       m->arena_next = host_next;                              // (the mirror is refreshed by the read-back below)
-      hipLaunchKernelGGL(k_rebal, dim3(64), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
-      hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl);
+      hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
       // the retry: lane per op over the device-side list (its length is ctl->n_prev), grid for 4x the previous batch's
       const uint32_t est_nd = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n);
       uint32_t* dl1 = m->defer[1].p;
