@@ -7,7 +7,7 @@ from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
 prof = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 B = 1 << 24
 dev = torch.device("cuda", 0)
-gen = Stream("zipf", 12345, 1000000, 1.1, 1)
+gen = Stream("zipf", 12345, 1000000, 1.1, int(os.environ.get("SMX_SCRAMBLE", "1")))
 xs = torch.empty((24, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
 stream = torch.cuda.current_stream().cuda_stream
 for s in range(24):
