@@ -276,84 +276,175 @@ struct ScalarReq {
 //    keys behind the cut, and neither may a cached entry);
 //  * batch writes drop it as well (they may touch mirrored cells).
 struct CellCache {
-  static constexpr unsigned SHARDS = 64;
-  struct Ent { uint32_t x, y, val, state; };          // state: 0 empty, 1 clean, 2 dirty
-  struct Shard {
-    std::mutex mu;
-    std::vector<Ent> tab;                              // open addressing, power of two
-    size_t used = 0, dirty = 0;
+  // Round 3: calls on mirrored cells take NO lock.  JVM threads hammer a few hundred shared cells
+  // (src/smatrix_benchmark.c:29-65: overlapping id blocks); behind one mutex per shard eight threads spent their time
+  // in futex waits (1 M gets: 95-190 ms against the reference's 27 ms, whose readers only bump a counter).  Now:
+  //  * an entry is {key, word} of two 64-bit atomics in a table that is allocated once at full size and never moves;
+  //    word = value | (generation << 2 | state) << 32 with state 0 empty / 1 clean / 2 dirty;
+  //  * get = one load of the word; set / incr / decr = ONE compare-and-swap of the word (new value, state dirty), so
+  //    every caller gets the value after ITS op (:230/:241/:252, wrapping), exactly, under any interleaving;
+  //  * inserts and wipes are the rare, locked operations (shard mutex; their callers hold the matrix lock);
+  //  * a drain takes an entry's dirty value with an exchange-like CAS of the whole word -- dirty -> clean when the
+  //    mirror is kept, -> empty when it is dropped -- so a write either lands before (and is in the drained value) or
+  //    finds the word changed and starts over / takes the slow path: nothing is lost, nobody waits;
+  //  * the generation (bumped by every wipe of the shard) keeps a write that was aimed at a forgotten entry from
+  //    landing on whatever was mirrored in that slot afterwards.
+  static constexpr unsigned SHARDS = 16;
+  static constexpr size_t SLOTS = (size_t)1 << 18;     // per shard, fixed (4 MB of zero pages, touched as they fill)
+  struct Ent {
+    std::atomic<uint64_t> key;                          // x << 32 | y
+    std::atomic<uint64_t> word;                         // value | (generation << 2 | state) << 32
   };
+  static uint32_t w_val(uint64_t w) { return (uint32_t)w; }
+  static uint32_t w_state(uint64_t w) { return (uint32_t)(w >> 32) & 3u; }
+  static uint64_t w_make(uint32_t val, uint32_t gen, uint32_t state) { return (uint64_t)val | ((uint64_t)((gen << 2) | state) << 32); }
+  struct alignas(64) Shard {
+    std::atomic<uint32_t> dirty{0};                     // entries that went clean -> dirty since the last drain (a hint)
+    uint32_t gen = 1;                                   // bumped by every wipe (30 bits are kept in the words)
+    std::mutex mu;                                      // insert / wipe
+    Ent* tab = nullptr;                                 // SLOTS entries, calloc'ed at the first insert
+    std::vector<uint32_t> occ;                          // occupied slots (what a drain walks)
+  };
+  struct alignas(64) Stripe { std::atomic<uint64_t> n{0}; };
   Shard sh[SHARDS];
+  Stripe hit_stripes[64];                               // hit counts, striped by thread: the counter must not become the shared line
   bool enabled = true;
-  size_t shard_cap = (size_t)1 << 16;                  // entries per shard before the shard is recycled (4 M cells in all)
-  std::atomic<uint64_t> hits{0}, flushes{0}, flushed_cells{0};
+  size_t shard_cap = (size_t)1 << 17;                   // entries per shard before the shard is recycled (2 M cells in all)
+  std::atomic<uint64_t> flushes{0}, flushed_cells{0};
+  ~CellCache() { for (Shard& s : sh) free(s.tab); }
 
+  uint64_t hits_total() const { uint64_t t = 0; for (const Stripe& s : hit_stripes) t += s.n.load(std::memory_order_relaxed); return t; }
+  void count_hit() {
+    static std::atomic<uint32_t> next{0};
+    thread_local uint32_t mine = next.fetch_add(1, std::memory_order_relaxed) & 63u;
+    hit_stripes[mine].n.fetch_add(1, std::memory_order_relaxed);
+  }
   static uint64_t mix(uint32_t x, uint32_t y) {
     uint64_t z = ((uint64_t)x << 32 | y) * 0x9e3779b97f4a7c15ULL;
     z ^= z >> 29; z *= 0xbf58476d1ce4e5b9ULL; z ^= z >> 32;
     return z;
   }
-  static Ent* find(Shard& s, uint64_t h, uint32_t x, uint32_t y) {
-    if (s.tab.empty()) return nullptr;
-    const size_t msk = s.tab.size() - 1;
-    for (size_t i = (h >> 6) & msk;; i = (i + 1) & msk) {
-      Ent& e = s.tab[i];
-      if (!e.state) return nullptr;
-      if (e.x == x && e.y == y) return &e;
+  // the entry of `key`, or nullptr; *w = its word as seen (state != 0)
+  static Ent* find(Shard& s, uint64_t h, uint64_t key, uint64_t* w) {
+    Ent* tab = s.tab;
+    if (!tab) return nullptr;
+    for (size_t i = (h >> 4) & (SLOTS - 1);; i = (i + 1) & (SLOTS - 1)) {
+      Ent& e = tab[i];
+      const uint64_t word = e.word.load();
+      if (w_state(word) == 0) return nullptr;
+      if (e.key.load(std::memory_order_relaxed) == key) { *w = word; return &e; }
     }
   }
   // the host arithmetic of one op on a mirrored cell; false = not mirrored
   bool apply(int op, uint32_t x, uint32_t y, uint32_t v, uint32_t* res) {
     if (!enabled || y == 0) return false;
-    const uint64_t h = mix(x, y);
+    const uint64_t h = mix(x, y), key = (uint64_t)x << 32 | y;
     Shard& s = sh[h & (SHARDS - 1)];
-    std::lock_guard<std::mutex> g(s.mu);
-    Ent* e = find(s, h, x, y);
+    uint64_t w;
+    Ent* e = find(s, h, key, &w);
     if (!e) return false;
-    if (op != OP_GET) {
-      e->val = op == OP_SET ? v : op == OP_INCR ? e->val + v : e->val - v;
-      if (e->state != 2) { e->state = 2; s.dirty++; }
+    if (op == OP_GET) {
+      if (e->key.load(std::memory_order_relaxed) != key) return false;          // (recycled between the two loads of find)
+      // (a frozen entry -- state 3, put() is recycling the shard -- still holds the cell's value)
+      *res = w_val(w);
+      count_hit();
+      return true;
     }
-    *res = e->val;
-    hits.fetch_add(1, std::memory_order_relaxed);
-    return true;
+    for (;;) {
+      if (w_state(w) == 3) return false;                                        // frozen: the shard is being recycled
+      const uint32_t nv = op == OP_SET ? v : op == OP_INCR ? w_val(w) + v : w_val(w) - v;
+      const uint64_t nw = (w & 0xFFFFFFFC00000000ull) | ((uint64_t)2 << 32) | nv;   // same generation, dirty, new value
+      if (e->word.compare_exchange_weak(w, nw)) {
+        if (w_state(w) == 1) s.dirty.fetch_add(1, std::memory_order_relaxed);
+        *res = nv;
+        count_hit();
+        return true;
+      }
+      // the word changed under us: another writer (go again on its value), a drain that kept the entry (state 1 now:
+      // go again), or a wipe (state 0 / another generation: this key is no longer mirrored here)
+      if (w_state(w) == 0 || ((w ^ nw) >> 34) != 0 || e->key.load(std::memory_order_relaxed) != key) return false;
+    }
+  }
+  void wipe_locked(Shard& s) {                          // caller holds s.mu
+    for (uint32_t i : s.occ) s.tab[i].word.store(0);
+    s.occ.clear();
+    s.dirty.store(0, std::memory_order_relaxed);
+    s.gen = (s.gen + 1) & 0x3FFFFFFFu;
+    if (s.gen == 0) s.gen = 1;
   }
   // the device holds `val` in cell (x,y): mirror it (clean).  Caller holds the matrix lock.
   void put(uint32_t x, uint32_t y, uint32_t val) {
     if (!enabled || y == 0) return;
-    const uint64_t h = mix(x, y);
+    const uint64_t h = mix(x, y), key = (uint64_t)x << 32 | y;
     Shard& s = sh[h & (SHARDS - 1)];
     std::lock_guard<std::mutex> g(s.mu);
-    if (s.tab.empty()) s.tab.assign(1024, Ent{0, 0, 0, 0});
-    if (Ent* e = find(s, h, x, y)) { if (e->state == 1) e->val = val; return; }   // (a dirty entry is newer than the device)
-    if (s.used >= shard_cap && s.dirty == 0) { std::fill(s.tab.begin(), s.tab.end(), Ent{0, 0, 0, 0}); s.used = 0; }
-    if (s.used >= shard_cap) return;                                             // full of dirty cells: until the next flush
-    if ((s.used + 1) * 2 > s.tab.size()) {
-      std::vector<Ent> old(s.tab.size() * 2, Ent{0, 0, 0, 0});
-      old.swap(s.tab);
-      const size_t msk = s.tab.size() - 1;
-      for (const Ent& e : old)
-        if (e.state) {
-          size_t i = (mix(e.x, e.y) >> 6) & msk;
-          while (s.tab[i].state) i = (i + 1) & msk;
-          s.tab[i] = e;
-        }
+    if (!s.tab) {
+      s.tab = static_cast<Ent*>(calloc(SLOTS, sizeof(Ent)));          // all-zero = all empty
+      if (!s.tab) smx_die("malloc() failed");
     }
-    const size_t msk = s.tab.size() - 1;
-    size_t i = (h >> 6) & msk;
-    while (s.tab[i].state) i = (i + 1) & msk;
-    s.tab[i] = Ent{x, y, val, 1};
-    s.used++;
+    uint64_t w;
+    if (Ent* e = find(s, h, key, &w)) {                                 // (a dirty entry is newer than the device)
+      if (w_state(w) == 1) e->word.compare_exchange_strong(w, (w & 0xFFFFFFFF00000000ull) | val);   // (lost to a writer: its value is newer)
+      return;
+    }
+    if (s.occ.size() >= shard_cap) {
+      // full: recycle the shard, all or nothing.  Every clean entry is FROZEN first (state 3: readers still use it, writers
+      // take the slow path -- which waits for the matrix lock our caller holds); one dirty entry and everything is thawed
+      // again (its value has to reach the device first: until the next drain has been through).  Only a completely
+      // frozen shard is wiped: a half-wiped one would hide entries behind cut probe sequences while they are still live.
+      size_t frozen = 0;
+      bool dirty_found = false;
+      for (; frozen < s.occ.size() && !dirty_found; frozen++) {
+        Ent& e = s.tab[s.occ[frozen]];
+        uint64_t w = e.word.load();
+        for (;;) {
+          if (w_state(w) == 2) { dirty_found = true; break; }
+          if (e.word.compare_exchange_weak(w, w | ((uint64_t)3 << 32))) break;      // 1 -> 3
+        }
+        if (dirty_found) break;
+      }
+      if (dirty_found) {
+        for (size_t k = 0; k < frozen; k++) {
+          Ent& e = s.tab[s.occ[k]];
+          e.word.store(e.word.load() & ~((uint64_t)2 << 32));                         // 3 -> 1 (nobody else writes a frozen word)
+        }
+        return;
+      }
+      wipe_locked(s);
+    }
+    size_t i = (h >> 4) & (SLOTS - 1);
+    while (w_state(s.tab[i].word.load(std::memory_order_relaxed))) i = (i + 1) & (SLOTS - 1);
+    s.tab[i].key.store(key, std::memory_order_relaxed);
+    s.tab[i].word.store(w_make(val, s.gen, 1));                         // published
+    s.occ.push_back((uint32_t)i);
   }
   // dirty cells -> out (marked clean); clear: forget everything afterwards.  Caller holds the matrix lock.
   void drain(std::vector<uint32_t>& xs, std::vector<uint32_t>& ys, std::vector<uint32_t>& vs, bool clear) {
     for (Shard& s : sh) {
+      if (!s.tab || s.occ.empty()) continue;
       std::lock_guard<std::mutex> g(s.mu);
-      if (s.dirty)
-        for (Ent& e : s.tab)
-          if (e.state == 2) { xs.push_back(e.x); ys.push_back(e.y); vs.push_back(e.val); e.state = 1; }
-      s.dirty = 0;
-      if (clear && s.used) { std::fill(s.tab.begin(), s.tab.end(), Ent{0, 0, 0, 0}); s.used = 0; }
+      if (!clear && !s.dirty.load(std::memory_order_acquire)) continue;
+      s.dirty.store(0, std::memory_order_release);
+      for (uint32_t i : s.occ) {
+        Ent& e = s.tab[i];
+        uint64_t w = e.word.load();
+        for (;;) {
+          if (!clear && w_state(w) != 2) break;
+          const uint64_t nw = clear ? 0ull : (w & 0xFFFFFFFC00000000ull) | ((uint64_t)1 << 32) | w_val(w);
+          if (e.word.compare_exchange_weak(w, nw)) {                    // took exactly the value that was there
+            if (w_state(w) == 2) {
+              const uint64_t k = e.key.load(std::memory_order_relaxed);
+              xs.push_back((uint32_t)(k >> 32)); ys.push_back((uint32_t)k); vs.push_back(w_val(w));
+            }
+            break;
+          }
+        }
+      }
+      if (clear) {
+        s.occ.clear();
+        s.gen = (s.gen + 1) & 0x3FFFFFFFu;
+        if (s.gen == 0) s.gen = 1;
+      }
     }
   }
 };
@@ -1185,6 +1276,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipHostMalloc(&m->h_small, 64));
   HIP_OK(hipHostMalloc(&m->h_row, 32 + (size_t)SCALAR_ROW_PAIRS_ALLOC * 8));
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
+  if (const char* a = getenv("SMATRIX_SCALAR_CACHE_CAP")) m->cache.shard_cap = std::max<size_t>(4, std::min<size_t>(strtoull(a, nullptr, 10), CellCache::SLOTS / 2));   // (tests: constant recycling)
   HIP_OK(hipEventCreate(&m->ev0));
   HIP_OK(hipEventCreate(&m->ev1));
   if (const char* a = getenv("SMATRIX_GROW_FORK")) m->grow_fork = *a != '0';
@@ -1836,7 +1928,7 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   for (uint32_t c = 0; c < N_CLASSES; c++)
     if (m->free_cnt[c] > 0) m->st.arena_free_units += (uint64_t)m->free_cnt[c] * block_units(c + ROW_FIRST_LG);
   m->st.arena_mapped = m->arena.mapped;
-  m->st.scalar_cache_hits = m->cache.hits.load();
+  m->st.scalar_cache_hits = m->cache.hits_total();
   m->st.scalar_cache_flushes = m->cache.flushes.load();
   m->st.scalar_cache_flushed_cells = m->cache.flushed_cells.load();
   m->st.file_leaked_bytes = m->file_index ? file_leaked(m) : 0;

@@ -331,3 +331,54 @@ def test_batch_of_more_than_2_to_31_ops():
     m.close()
     del x, rows, lens
     libsmatrix_amd._lib.load().smatrix_release_cached_memory()
+
+
+@pytest.mark.parametrize("cap", [None, "48"])
+def test_scalar_mirror_lock_free_under_threads(G, monkeypatch, cap):
+    """The scalar ABI's host mirror takes no lock on mirrored cells (one compare-and-swap per write): 8 threads do
+    240 000 incr / decr / get calls on 3000 shared cells while a background flusher-like thread keeps forcing
+    write-backs (batch gets drain the mirror) and -- cap = 48 entries per shard -- the mirror is recycled all the time
+    (freeze, wipe, new generation).  Every increment must survive: final values == the sums of what the calls added,
+    and every incr must have returned a value some serialisation allows (strictly positive, <= the cell's final)."""
+    if cap:
+        monkeypatch.setenv("SMATRIX_SCALAR_CACHE_CAP", cap)
+    import threading
+    g = G()
+    rng = np.random.default_rng(77)
+    cx = rng.integers(1, 200, 3000, dtype=np.uint32); cy = rng.integers(1, 5000, 3000, dtype=np.uint32)
+    cells = np.unique(cx.astype(np.uint64) << 32 | cy)
+    cx, cy = (cells >> 32).astype(np.uint32), (cells & 0xFFFFFFFF).astype(np.uint32)
+    T, N = 8, 30000
+    picks = [np.random.default_rng(100 + t).integers(0, cells.size, N) for t in range(T)]
+    adds = [np.random.default_rng(200 + t).integers(1, 5, N).astype(np.uint32) for t in range(T)]
+    rets = [np.zeros(N, np.uint32) for _ in range(T)]
+    stop = threading.Event()
+
+    def work(t):
+        for k in range(N):
+            i = int(picks[t][k])
+            rets[t][k] = g.incr(int(cx[i]), int(cy[i]), int(adds[t][k]))
+            if k % 7 == 0:
+                g.get(int(cx[i]), int(cy[i]))
+
+    def disturb():
+        while not stop.is_set():
+            g.m.get_batch(cx[:64], cy[:64])                  # a table read: the mirror is written back first
+            time.sleep(0.002)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)] + [threading.Thread(target=disturb)]
+    for t in th:
+        t.start()
+    for t in th[:-1]:
+        t.join()
+    stop.set(); th[-1].join()
+    want = np.zeros(cells.size, np.uint64)
+    for t in range(T):
+        np.add.at(want, picks[t], adds[t].astype(np.uint64))
+    got = g.m.get_batch(cx, cy)
+    assert (got == want.astype(np.uint32)).all()
+    for t in range(T):
+        assert (rets[t] >= adds[t]).all() and (rets[t] <= want[picks[t]]).all()
+    st = g.stats()
+    assert st["scalar_cache_hits"] > 100000, st
+    g.close()
