@@ -526,7 +526,17 @@ def run_config5(torch, dev, rows=None, path=None):
     if os.path.exists(path):
         os.remove(path)
     touch_hbm(torch, dev, rows * 256 * 8 * 1.6)
-    m = SparseMatrix(path)
+    # the background flusher (SMATRIX_FLUSH_MS, default 100 ms) would write most rows while the table is still being built
+    # and scanned; it is switched off here so that close_s is the cost of persisting the WHOLE matrix, as in rounds 1-2
+    keep = os.environ.get("SMATRIX_FLUSH_MS")
+    os.environ["SMATRIX_FLUSH_MS"] = "0"
+    try:
+        m = SparseMatrix(path)
+    finally:
+        if keep is None:
+            os.environ.pop("SMATRIX_FLUSH_MS", None)
+        else:
+            os.environ["SMATRIX_FLUSH_MS"] = keep
     build_cf(torch, dev, m, rows)
     before = scan_cf(torch, dev, m, rows, 1)
     gen = Stream("cf", SEED, CF_COLS, float(CF_PER_ROW), 1)
@@ -752,6 +762,7 @@ def main():
                     help="config 2 only: skip the legs that are not `value` (reference-checksum replay, sustained run, dense ids, configs 3/5)")
     ap.add_argument("--no-reserve", action="store_true", help="do not map the row arena up front (A/B of smatrix_reserve)")
     ap.add_argument("--sustain-s", type=float, default=1.5, help="seconds of the sustained (continuing-stream) leg")
+    ap.add_argument("--batch-leg", type=int, default=0, help="extra leg: the same stream in batches of 2^N ops (e.g. 26), not part of the default run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -985,6 +996,8 @@ def main():
     ok = bool((out_g >= 1).all().item())
 
     extras = {}
+    if not sharded and args.batch_leg:
+        extras["batch_2_%d" % args.batch_leg] = guarded(batch_size_leg, torch, dev, args.batch_leg, stream)
     if not sharded and not args.no_extras and args.batch_lg == BATCH_LG:
         # (1) the reference-held checksums of this very stream, on a fresh matrix (outside the timed region)
         # (2) sustained leg: the SAME step on the continuing stream (fresh batches, table keeps growing) for >= 1 s of
@@ -999,8 +1012,6 @@ def main():
         extras["dense_ids"] = guarded(dense_ids_leg, torch, dev, B, stream)
         # (4) the four op kinds on the finished table
         extras["op_kinds"] = guarded(op_kinds_leg, torch, dev, m, xs[total_steps - 1], ys[total_steps - 1], B, stream)
-        # (5) the same stream in 2^26-op batches (the upper end of SURVEY 8d's range): per-batch fixed costs shared by 4x the ops
-        extras["batch_2_26"] = guarded(batch_size_leg, torch, dev, 26, stream)
 
     total_ops = 2 * B * args.steps * world
     res = {

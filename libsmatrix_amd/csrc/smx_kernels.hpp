@@ -2111,10 +2111,21 @@ __global__ __launch_bounds__(256) void k_set_store(uint32_t n, const uint64_t* c
     reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = vs[(size_t)j * st];
 }
 
-// the same five passes over the ENTRIES of k_set_fold (ent_idx[e] = winner's op index + 1, 0 = no entry)
-__global__ __launch_bounds__(256) void k_set_locate_e(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_ent,
-                                                      const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
-                                                      uint32_t* ent_idx, uint64_t* ent_cell, uint32_t st) {
+// the ENTRIES of k_set_fold (ent_idx[e] = winner's op index + 1, 0 = no entry):
+// Round 3: the order across tiles in THREE passes and one atomic per entry on a compact side array, instead of four passes
+// with the atomic on the table.  The cell's value word is free during a set batch (it is about to be overwritten), so
+// the entries of one key MEET there:
+//   meet   every entry finds its cell and stores its own id in the value word (plain stores: one of them stays) and
+//          zeroes its slot of the side array
+//   rank   every entry reads the id E that stayed -- the key's representative -- and folds {op index, value} into
+//          side[E] with ONE 64-bit atomicMax: the highest op index wins and brings its value along; entries other than
+//          E are done
+//   store  the representatives write the low half of their side slot into the cell
+// (an entry never has to recognise "its" index in a word that may already hold a value: the hazard that kept pick and
+//  store apart -- a value that happens to equal a loser's index -- does not exist here)
+__global__ __launch_bounds__(256) void k_set_meet_e(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_ent,
+                                                    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+                                                    uint32_t* ent_idx, uint64_t* ent_cell, unsigned long long* side, uint32_t st) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t w1 = e < n_ent ? ent_idx[e] : 0u;
   const bool live = w1 != 0;
@@ -2145,22 +2156,24 @@ __global__ __launch_bounds__(256) void k_set_locate_e(DirSlot* dir, uint32_t dma
   }
   if (live) {
     ent_cell[e] = where;
+    side[e] = 0ull;
     if (where == ~0ull) ent_idx[e] = 0;
-    else reinterpret_cast<uint32_t*>(arena)[where * 2 + 1] = 0;          // (k_set_clear's job, done here)
+    else reinterpret_cast<uint32_t*>(arena)[where * 2 + 1] = e + 1u;
   }
 }
-__global__ __launch_bounds__(256) void k_set_rank_e(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena) {
+__global__ __launch_bounds__(256) void k_set_rank_e2(uint32_t n_ent, uint32_t* ent_idx, const uint64_t* ent_cell, const uint8_t* arena,
+                                                     unsigned long long* side, const uint32_t* __restrict__ vs, uint32_t st) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_ent && ent_idx[e]) atomicMax(&reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1], ent_idx[e]);
+  if (e >= n_ent || !ent_idx[e]) return;
+  const uint32_t idx = ent_idx[e];
+  const uint32_t E = reinterpret_cast<const uint32_t*>(arena)[ent_cell[e] * 2 + 1] - 1u;
+  atomicMax(&side[E], ((unsigned long long)idx << 32) | vs[(size_t)(idx - 1u) * st]);
+  if (E != e) ent_idx[e] = 0;                          // not the representative: done
 }
-__global__ __launch_bounds__(256) void k_set_pick_e(uint32_t n_ent, uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena) {
+__global__ __launch_bounds__(256) void k_set_store_e2(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena,
+                                                      const unsigned long long* side) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_ent && ent_idx[e] && reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] != ent_idx[e]) ent_idx[e] = 0;   // loser
-}
-__global__ __launch_bounds__(256) void k_set_store_e(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell,
-                                                     const uint32_t* __restrict__ vs, uint8_t* arena, uint32_t st) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_ent && ent_idx[e]) reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = vs[(size_t)(ent_idx[e] - 1u) * st];
+  if (e < n_ent && ent_idx[e]) reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = (uint32_t)side[e];
 }
 
 // ---- directory growth -----------------------------------------------------------
