@@ -540,6 +540,7 @@ struct Matrix {
   // the speculative chain (run_write): on when the previous write batch was finished by its round 1
   bool spec_enabled = true;             // SMATRIX_SPEC=0 switches it off
   bool spec_ready = false;
+  bool spec_tiny = false;               // SMATRIX_SPEC_TINY=1 (tests)
   uint32_t spec_nd_prev = 0, spec_nt_prev = 0, spec_nk_prev[4] = {0, 0, 0, 0};   // the previous batch's round 0: deferred ops, growth tasks (by kind)
   uint64_t spec_gu_prev = 0;            // ... and the units its growths took
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
@@ -745,7 +746,8 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   // chunk bounds: a table of 2^lg cells has max(1, 2^lg/64) chunks; units = 2^lg/16
   m->map_new.need((size_t)nt + gu / 4 + 1);
   m->map_old.need((size_t)nt + gu / 8 + 1);
-  const uint64_t cap_units = m->arena.mapped / UNIT_BYTES;
+  uint64_t cap_units = m->arena.mapped / UNIT_BYTES;
+  if (spec && m->spec_tiny) cap_units = std::min<uint64_t>(cap_units, m->arena_next + gu);   // (tests: arena refusals too)
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, nt, s);     // every task retires one block
   // (spec: the arena holds gu units beyond the host's mirror of the bump pointer -- row creation in prep may have taken
   //  some of the slack ensure_arena_free was asked for, hence the cap is what is mapped, checked per allocation)
@@ -932,8 +934,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     uint32_t* dl = m->defer[round & 1].p;
     const bool chained = chain && round == 0;
     // estimates for the chain's growth round: four times what the previous batch needed (k_grow_plan refuses the rest)
-    const uint32_t est_nt = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nt_prev, 1u << 16), std::min<uint64_t>(cur_n, m->dir_size));
-    const uint64_t est_gu = std::max<uint64_t>(2 * m->spec_gu_prev, 1ull << 20);
+    // (SMATRIX_SPEC_TINY=1, tests: estimates far too small, so that k_grow_plan's refusals and the hand-over to the host-driven
+    //  loop are exercised on every chained batch)
+    const uint32_t est_nt = m->spec_tiny ? 5u : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nt_prev, 1u << 16), std::min<uint64_t>(cur_n, m->dir_size));
+    const uint64_t est_gu = m->spec_tiny ? 24u : std::max<uint64_t>(2 * m->spec_gu_prev, 1ull << 20);
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room) + (chained ? est_gu : 0), s);
     ctl_reset_round(m, s);
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
@@ -1306,6 +1310,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_DBG_AFTER")) m->dbg_after = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SPEC")) m->spec_enabled = *a != '0';
+  if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_FSYNC")) m->file_fsync = *a == '1';

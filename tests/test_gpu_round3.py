@@ -382,3 +382,42 @@ def test_scalar_mirror_lock_free_under_threads(G, monkeypatch, cap):
     st = g.stats()
     assert st["scalar_cache_hits"] > 100000, st
     g.close()
+
+
+@pytest.mark.parametrize("tiny", [False, True])
+def test_speculative_chain_and_its_refusals(G, oracle_mod, monkeypatch, tiny):
+    """run_write enqueues rounds 0 and 1 of a steady-state batch at once (op kernel, prep, growth passes sized from the
+    previous batch, the retry over the device-side list, prep) and reads back once.  tiny: the estimates are forced far
+    too small (5 growth tasks, 24 arena units), so that on every chained batch k_grow_plan REFUSES most rows -- they keep
+    their tables, their ops stay deferred -- and the host-driven loop finishes the batch.  Either way values, per-key
+    return multisets, row sizes and rowlens are the oracle's; directory growth and brand-new rows in the middle of it."""
+    if tiny:
+        monkeypatch.setenv("SMATRIX_SPEC_TINY", "1")
+    rng = np.random.default_rng(314)
+    g, o = G(), oracle_mod.Oracle()
+    nrows = 3000
+    for rnd in range(24):
+        n = 60000
+        if rnd == 12:
+            nrows = 200000                                           # new rows by the 10^5 in one batch: the directory has to grow
+        x = rng.integers(0, nrows, n, dtype=np.uint32)
+        y = rng.integers(1, 120 + 8 * rnd, n, dtype=np.uint32)       # mostly present keys, some new ones in every batch: the steady shape
+        if rnd % 5 == 4:                                             # a few giant rows crossing thresholds (chunked growth, big-row quotas)
+            x[: n // 2] = rng.integers(0, 3, n // 2, dtype=np.uint32)
+        v = ((x * 5 + y) % 3 + 1).astype(np.uint32)
+        op = 3 if rnd == 6 else 2
+        if rnd == 12:
+            x, y, v = x[:30000], y[:30000], v[:30000]
+        a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
+        k = x.astype(np.uint64) << 32 | y
+        assert (a[np.lexsort((a, k))] == b[np.lexsort((b, k))]).all(), rnd
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rnd
+    st = g.stats()
+    assert st["spec_chains"] >= 6, st
+    assert (st["spec_refused"] >= 4) if tiny else (st["spec_refused"] == 0), st
+    rows = o.list_rows()
+    assert st["rows"] == rows.size
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    for r in rows[:100].tolist() + [0, 1, 2]:
+        assert g.row_info(r) == o.row_info(r), r
+    g.close(); o.close()
