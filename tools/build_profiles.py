@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Turns the raw outputs of tools/refresh_profiles.sh (gpurun_out/prof_*) into the files committed under profiles/:
-r02_bench.json, r02_rocprof_kernel_stats.txt, r02_pmc_summary.txt, pmc.json (keyed to the kernel source hash), r02_getrow_config3.txt."""
+r03_bench.json, r03_rocprof_kernel_stats.txt, r03_pmc_summary.txt, pmc.json (keyed to the kernel source hash), r03_getrow_config3.txt."""
 import hashlib, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = "r02"
+RND = "r03"
 
 
 def kernel_source_sha16():
@@ -36,7 +36,7 @@ rd_agg = agg["miss"] - agg["atom"]
 t_agg = rd_agg / (R * 1e9) + agg["atom"] / (A * 1e9); t_get = get["miss"] / (R * 1e9)
 ki, kg = b["roofline"]["avg_launch_ms"], b["roofline_get"]["avg_launch_ms"]
 hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --no-cpu --no-extras   (three separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; tools/refresh_profiles.sh + tools/build_profiles.py)
-# MI355X, round 2, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
+# MI355X, round 3, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
 # Calibration in our own access pattern, same runs: k_probe_random<0> = 2^27 random 8-byte loads over 4 GiB -> %.0f KiB = %.1f B per touch
 #   (a 64 B line per touch; no 1/2 correction for this shape); k_probe_random<1>/<2> = 2^27 scattered 32-bit atomics -> WRITE_SIZE 32 B and TCC_EA0_ATOMIC 1.0 per atomic.
 #   (the guide's gfx950 correction -- FETCH_SIZE tallies a 128-B coalesced streaming request at 64 B -- applies only to the streamed op arrays,
@@ -50,7 +50,7 @@ hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- pytho
 # so the read misses of the incr kernel are TCC_MISS - TCC_EA0_ATOMIC; they include the streamed op arrays (12 B/op in = 3.1 M lines).
 #   k_apply_agg<INCR>: %.1f M read misses / %.1f G/s + %.1f M atomics / %.1f G/s = %.3f ms;  measured %.3f ms per launch (HIP events, growing table;
 #                      1.30 ms when every key is a hit) -> %.0f %% of that bound.  The atomics are 80 %% of it: one returning atomic per distinct key of a
-#                      2048-op tile (+ a ticket and a claim per new cell) -- the LDS fold removes the duplicates inside a tile, not across tiles
+#                      2048-op tile (+ a ticket and a claim per new cell: tools/probe/tile_fold_census.py counts 15.0 M + 3.8 M + 3.8 M for batch 15) -- the LDS fold removes the duplicates inside a tile, not across tiles
 #                      (how the kernel's time splits over these classes: profiles/r02_agg_kernel_phase_shares.txt).
 #   k_apply<GET>     : %.1f M misses / %.1f G/s = %.3f ms;  measured %.3f ms -> %.0f %%
 #   i.e. the kernels run within 15-30 %% of the chip's random-transaction rates for what they touch; the rest of the gap to the byte roofline is the COUNT
@@ -68,7 +68,7 @@ json.dump({"summary": "profiles/%s_pmc_summary.txt" % RND, "kernel_source_sha16"
                            "l2_misses": get["miss"]}}, open(os.path.join(P, "pmc.json"), "w"), indent=1)
 ur = json.load(open(os.path.join(G, "prof_bench_under_rocprof.json")))
 open(os.path.join(P, RND + "_rocprof_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 2, tools/refresh_profiles.sh; bench line of this "
+    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 3, tools/refresh_profiles.sh; bench line of this "
     "same profiled run: %.0f Mops/s, k_apply_agg<INCR> round-0 avg %.3f ms and k_apply<GET> %.3f ms by HIP events; the full-batch grids below include the 4 all-hit "
     "replays of the steady-state extra and the first batches of the empty table)\n" % (ur["value"], ur["roofline"]["avg_launch_ms"], ur["roofline_get"]["avg_launch_ms"])
     + open(os.path.join(G, "prof_kernel_stats.txt")).read()
@@ -90,13 +90,13 @@ c3 = json.load(open(os.path.join(G, "prof_bench_config3_under_rocprof.json")))
 
 
 def val3(kern, ctr):
-    m = re.search(r"%s\s+grid=\d+\s+%s\s+dispatches=\s*(\d+) mean=\s*([\d.]+)" % (re.escape(kern), ctr), raw3)
+    m = re.search(r"%s(?:<[^>]*>)?\s+grid=\d+\s+%s\s+dispatches=\s*(\d+) mean=\s*([\d.]+)" % (re.escape(kern), ctr), raw3)
     return float(m.group(2)) if m else None
 
 
 f3, w3 = val3("smx::k_getrow", "FETCH_SIZE"), val3("smx::k_getrow", "WRITE_SIZE")
 d3 = c3["detail"]
-lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 2" % (d3["rows"], d3["nnz"]),
+lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 3" % (d3["rows"], d3["nnz"]),
          "# bench line of the profiled run: getrow %.3f ms = %.1f G nnz/s; algorithmic %.0f GB/s = %.3f of the 8 TB/s peak; build %.2f s (%.2f G ops/s)"
          % (d3["getrow_ms"], d3["Gnnz_per_s"], d3["roofline"]["achieved"], d3["roofline"]["frac"], d3["build_s"], d3["build_Gops_per_s"])]
 if f3 and w3:
