@@ -106,6 +106,12 @@ int smatrix_shard_set_placement(smatrix_shard_t* sh, const uint32_t* cuts, const
 int smatrix_shard_get_placement(smatrix_shard_t* sh, uint32_t* cuts_out, uint32_t* n_cuts, uint32_t* place_pairs_out,
                                 uint32_t cap_rows, uint32_t* n_rows);
 
+/* the planner and the <file>.placement format without a device or a handle (tests; tools that want to inspect or prepare a
+ * placement): n samples {xs[i], counts[i] ops} of a stream of `total` ops -> the plan for `world` shards as JSON in out
+ * (cap bytes).  reparse != 0: parsed back and re-serialised first.  Returns the text's length, -1 on error. */
+int smatrix_shard_plan_json(const uint32_t* xs, const uint64_t* counts, size_t n, uint64_t total, int world, int reparse,
+                            char* out, size_t cap);
+
 /* op = SMATRIX_OP_* (smatrix_batch.h); d_v may be NULL for get */
 int smatrix_shard_apply_dev(smatrix_shard_t* sh, int op, size_t n, const uint32_t* d_x, const uint32_t* d_y,
                             const uint32_t* d_v, uint32_t* d_out, void* hip_stream);

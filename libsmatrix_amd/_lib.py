@@ -99,6 +99,7 @@ def load():
         "smatrix_shard_apply_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, V, V, V, V]),
         "smatrix_shard_apply_then_get_dev": (C.c_int, [V, C.c_int, C.c_size_t, V, V, V, V, V, V]),
         "smatrix_shard_transport": (C.c_char_p, [V]),
+        "smatrix_shard_plan_json": (C.c_int, [V, V, C.c_size_t, C.c_uint64, C.c_int, C.c_int, V, C.c_size_t]),
         "smatrix_shard_get_placement": (C.c_int, [V, V, V, V, C.c_uint32, V]),
         "smatrix_shard_route_dev": (V, [V, C.c_int, C.c_size_t, V, V, V, C.c_int, V]),
         "smatrix_shard_apply_routed": (C.c_int, [V, V, C.c_int, V]),

@@ -47,3 +47,42 @@ def test_plan_placement_balances_zipf():
     assert float(p[0]) * world > 0.99                      # why: the hottest row alone is one shard's fair share
     back = Placement.from_json(pl.to_json())
     assert back.cuts == pl.cuts and back.place == pl.place and back.world == world
+
+
+def test_c_planner_equals_python_planner():
+    """The C library's router plans its own placement (csrc/smx_shard.inc plan_placement) and stores it as the JSON the
+    Python router reads: on the same samples both planners must produce the SAME plan -- hot rows, owners, cut points --
+    for 2 to 8 shards, on the analytic Zipf marginal, on ties and on degenerate inputs; the C parser must round-trip it."""
+    import ctypes as C
+    import json
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from libsmatrix_amd import _lib
+    from libsmatrix_amd.sharded import Placement, plan_placement
+    lib = _lib.load()
+
+    def c_plan(counts, total, world, reparse):
+        xs = np.array(sorted(counts), dtype=np.uint32)
+        cs = np.array([counts[int(x)] for x in xs], dtype=np.uint64)
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.smatrix_shard_plan_json(xs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p), xs.size, total, world, reparse, buf, len(buf))
+        assert n > 0
+        return Placement.from_json(buf.value.decode())
+
+    rng = np.random.default_rng(8)
+    p = np.arange(1, 1000001) ** -1.1
+    p /= p.sum()
+    cases = []
+    for world in (2, 3, 4, 8):
+        total = world << 20
+        cases.append(({int(rng.integers(1, 1 << 32)) if k else 0xFFFFFFFF: int(p[k] * total) + 1 for k in range(700)}, total, world))
+        cases.append(({int(x): 7 for x in rng.integers(1, 1 << 31, 300)}, 5000, world))          # ties: broken by row id
+        cases.append(({5: 100}, 100, world))                                                     # one row is the whole stream
+        cases.append(({}, 0, world))                                                             # nothing sampled
+    for counts, total, world in cases:
+        want = plan_placement(dict(counts), total, world, 256)
+        for reparse in (0, 1):
+            got = c_plan(counts, total, world, reparse)
+            assert got.world == want.world == world
+            assert got.place == want.place, (world, len(counts))
+            assert got.cuts == want.cuts, (world, got.cuts, want.cuts)
