@@ -1713,17 +1713,16 @@ __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, ui
 // tasks, and a wave per task of ALL kinds made this trivial pass 40 us of the growth round's critical path)
 __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const GrowTask* tasks, const uint32_t* list,
                                               uint32_t* map_old, uint32_t* map_new) {
-  uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
-  uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
-  uint32_t lane = threadIdx.x & 63;
-  uint32_t nwaves = (g.nb * blockDim.x) >> 6;
-  for (uint32_t li = wave; li < n; li += nwaves) {
+  // one WORKGROUP per chunked task (a 2 M-slot row has 10^5 chunk entries: one wave writing them all was 30 us of the
+  // growth round's critical path)
+  const uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
+  for (uint32_t li = g.bid; li < n; li += g.nb) {            // block-uniform
     const uint32_t t = list[li];
     const GrowTask k = tasks[t];
     if (grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE) continue;   // (a range whose task got no block is
     const uint32_t oc = 1u << (k.old_lg - 6), nc = 2u * oc;                          //  still mapped: the passes skip it by new_base)
-    for (uint32_t c = lane; c < oc; c += 64) map_old[k.chunk0 + c] = t;
-    for (uint32_t c = lane; c < nc; c += 64) map_new[k.chunk0_new + c] = t;
+    for (uint32_t c = threadIdx.x; c < oc; c += blockDim.x) map_old[k.chunk0 + c] = t;
+    for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) map_new[k.chunk0_new + c] = t;
   }
 }
 __global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks, const uint32_t* list,

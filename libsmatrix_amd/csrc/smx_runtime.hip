@@ -779,7 +779,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     sc = m->helper;
   }
   if (n_chunked) {
-    hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(blocks_for((uint64_t)n_chunked * 64), 2048)),
+    hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 2048)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p);
     hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
