@@ -2114,8 +2114,12 @@ __global__ __launch_bounds__(256) void k_set_store(uint32_t n, const uint64_t* c
 // Round 3: the order across tiles in THREE passes and one atomic per entry on a compact side array, instead of four passes
 // with the atomic on the table.  The cell's value word is free during a set batch (it is about to be overwritten), so
 // the entries of one key MEET there:
-//   meet   every entry finds its cell and stores its own id in the value word (plain stores: one of them stays) and
-//          zeroes its slot of the side array
+//   meet   every entry finds its cell and stores its own id in the value word (one of them stays) and zeroes its slot of
+//          the side array.  The store is an AGENT-SCOPE ATOMIC store and rank reads the word with an agent-scope load:
+//          with plain stores, two entries of one key running on different XCDs each kept the line dirty in their own L2
+//          with their own id in it, and in the next kernel each read ITS id back -- two representatives for one key, the
+//          later store pass decided by chance (tests/soak.py caught it: ~100 wrong cells per 1.5 M-op Zipf batch).
+//          Conflicting plain stores to one word from different XCDs are not reconciled by a kernel boundary on this chip.
 //   rank   every entry reads the id E that stayed -- the key's representative -- and folds {op index, value} into
 //          side[E] with ONE 64-bit atomicMax: the highest op index wins and brings its value along; entries other than
 //          E are done
@@ -2155,9 +2159,9 @@ __global__ __launch_bounds__(256) void k_set_meet_e(DirSlot* dir, uint32_t dmask
   }
   if (live) {
     ent_cell[e] = where;
-    side[e] = 0ull;
+    __hip_atomic_store(&side[e], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (rank folds into it with atomics from every XCD)
     if (where == ~0ull) ent_idx[e] = 0;
-    else reinterpret_cast<uint32_t*>(arena)[where * 2 + 1] = e + 1u;
+    else __hip_atomic_store(&reinterpret_cast<uint32_t*>(arena)[where * 2 + 1], e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ __launch_bounds__(256) void k_set_rank_e2(uint32_t n_ent, uint32_t* ent_idx, const uint64_t* ent_cell, const uint8_t* arena,
@@ -2165,14 +2169,15 @@ __global__ __launch_bounds__(256) void k_set_rank_e2(uint32_t n_ent, uint32_t* e
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_ent || !ent_idx[e]) return;
   const uint32_t idx = ent_idx[e];
-  const uint32_t E = reinterpret_cast<const uint32_t*>(arena)[ent_cell[e] * 2 + 1] - 1u;
+  const uint32_t E = __hip_atomic_load(&reinterpret_cast<const uint32_t*>(arena)[ent_cell[e] * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
   atomicMax(&side[E], ((unsigned long long)idx << 32) | vs[(size_t)(idx - 1u) * st]);
   if (E != e) ent_idx[e] = 0;                          // not the representative: done
 }
 __global__ __launch_bounds__(256) void k_set_store_e2(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena,
                                                       const unsigned long long* side) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_ent && ent_idx[e]) reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = (uint32_t)side[e];
+  if (e < n_ent && ent_idx[e])
+    reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = (uint32_t)__hip_atomic_load(&side[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- directory growth -----------------------------------------------------------

@@ -421,3 +421,22 @@ def test_speculative_chain_and_its_refusals(G, oracle_mod, monkeypatch, tiny):
     for r in rows[:100].tolist() + [0, 1, 2]:
         assert g.row_info(r) == o.row_info(r), r
     g.close(); o.close()
+
+
+def test_set_batch_duplicates_across_many_tiles_zipf(G, oracle_mod):
+    """Highest-index-wins ACROSS the 2048-op tiles of k_set_fold on the shape that broke round 3's first version of the
+    entry passes: 1.5 M Zipf sets over 5000 rows (hot cells written from hundreds of tiles on all XCDs, rows growing while
+    the batch runs).  The entries of one key meet in the cell's value word; with plain stores two entries on different
+    XCDs each read their own id back and the key got two representatives (tests/soak.py: ~100 wrong cells per batch)."""
+    rng = np.random.default_rng(5)
+    n = 1500000
+    g, o = G(), oracle_mod.Oracle()
+    for rep in range(3):
+        x = (rng.zipf(1.3, n) % 5000).astype(np.uint32); y = (rng.zipf(1.2, n) % (1 << 22)).astype(np.uint32) + 1
+        v = rng.integers(1, 1 << 31, n, dtype=np.uint32)
+        kind = 1 if rep else 2
+        a, b = g.apply(kind, x, y, v), o.apply(kind, x, y, v)
+        if kind == 1:
+            assert (a == v).all()                                   # set returns what it was given (:230)
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rep
+    g.close(); o.close()
