@@ -380,7 +380,7 @@ def test_scalar_mirror_lock_free_under_threads(G, monkeypatch, cap):
     for t in range(T):
         assert (rets[t] >= adds[t]).all() and (rets[t] <= want[picks[t]]).all()
     st = g.stats()
-    assert st["scalar_cache_hits"] > 100000, st
+    assert st["scalar_cache_hits"] > (5000 if cap else 100000), st          # (cap: the mirror is wiped all the time, hits depend on timing)
     g.close()
 
 
