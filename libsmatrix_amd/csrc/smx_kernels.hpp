@@ -2110,25 +2110,10 @@ __global__ __launch_bounds__(256) void k_set_store(uint32_t n, const uint64_t* c
     reinterpret_cast<uint32_t*>(arena)[cellp[j] * 2 + 1] = vs[(size_t)j * st];
 }
 
-// the ENTRIES of k_set_fold (ent_idx[e] = winner's op index + 1, 0 = no entry):
-// Round 3: the order across tiles in THREE passes and one atomic per entry on a compact side array, instead of four passes
-// with the atomic on the table.  The cell's value word is free during a set batch (it is about to be overwritten), so
-// the entries of one key MEET there:
-//   meet   every entry finds its cell and stores its own id in the value word (one of them stays) and zeroes its slot of
-//          the side array.  The store is an AGENT-SCOPE ATOMIC store and rank reads the word with an agent-scope load:
-//          with plain stores, two entries of one key running on different XCDs each kept the line dirty in their own L2
-//          with their own id in it, and in the next kernel each read ITS id back -- two representatives for one key, the
-//          later store pass decided by chance (tests/soak.py caught it: ~100 wrong cells per 1.5 M-op Zipf batch).
-//          Conflicting plain stores to one word from different XCDs are not reconciled by a kernel boundary on this chip.
-//   rank   every entry reads the id E that stayed -- the key's representative -- and folds {op index, value} into
-//          side[E] with ONE 64-bit atomicMax: the highest op index wins and brings its value along; entries other than
-//          E are done
-//   store  the representatives write the low half of their side slot into the cell
-// (an entry never has to recognise "its" index in a word that may already hold a value: the hazard that kept pick and
-//  store apart -- a value that happens to equal a loser's index -- does not exist here)
-__global__ __launch_bounds__(256) void k_set_meet_e(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_ent,
-                                                    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
-                                                    uint32_t* ent_idx, uint64_t* ent_cell, unsigned long long* side, uint32_t st) {
+// the same five passes over the ENTRIES of k_set_fold (ent_idx[e] = winner's op index + 1, 0 = no entry)
+__global__ __launch_bounds__(256) void k_set_locate_e(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_ent,
+                                                      const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+                                                      uint32_t* ent_idx, uint64_t* ent_cell, uint32_t st) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t w1 = e < n_ent ? ent_idx[e] : 0u;
   const bool live = w1 != 0;
@@ -2159,26 +2144,29 @@ __global__ __launch_bounds__(256) void k_set_meet_e(DirSlot* dir, uint32_t dmask
   }
   if (live) {
     ent_cell[e] = where;
-    __hip_atomic_store(&side[e], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (rank folds into it with atomics from every XCD)
     if (where == ~0ull) ent_idx[e] = 0;
-    else __hip_atomic_store(&reinterpret_cast<uint32_t*>(arena)[where * 2 + 1], e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else reinterpret_cast<uint32_t*>(arena)[where * 2 + 1] = 0;          // (k_set_clear's job, done here)
   }
 }
-__global__ __launch_bounds__(256) void k_set_rank_e2(uint32_t n_ent, uint32_t* ent_idx, const uint64_t* ent_cell, const uint8_t* arena,
-                                                     unsigned long long* side, const uint32_t* __restrict__ vs, uint32_t st) {
+__global__ __launch_bounds__(256) void k_set_rank_e(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_ent || !ent_idx[e]) return;
-  const uint32_t idx = ent_idx[e];
-  const uint32_t E = __hip_atomic_load(&reinterpret_cast<const uint32_t*>(arena)[ent_cell[e] * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-  atomicMax(&side[E], ((unsigned long long)idx << 32) | vs[(size_t)(idx - 1u) * st]);
-  if (E != e) ent_idx[e] = 0;                          // not the representative: done
+  if (e < n_ent && ent_idx[e]) atomicMax(&reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1], ent_idx[e]);
 }
-__global__ __launch_bounds__(256) void k_set_store_e2(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena,
-                                                      const unsigned long long* side) {
+__global__ __launch_bounds__(256) void k_set_pick_e(uint32_t n_ent, uint32_t* ent_idx, const uint64_t* ent_cell, uint8_t* arena) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_ent && ent_idx[e])
-    reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = (uint32_t)__hip_atomic_load(&side[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (e < n_ent && ent_idx[e] && reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] != ent_idx[e]) ent_idx[e] = 0;   // loser
 }
+__global__ __launch_bounds__(256) void k_set_store_e(uint32_t n_ent, const uint32_t* ent_idx, const uint64_t* ent_cell,
+                                                     const uint32_t* __restrict__ vs, uint8_t* arena, uint32_t st) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_ent && ent_idx[e]) reinterpret_cast<uint32_t*>(arena)[ent_cell[e] * 2 + 1] = vs[(size_t)(ent_idx[e] - 1u) * st];
+}
+// (Round 3 tried three passes instead -- every entry stores its id in the cell's value word, one 64-bit atomicMax of
+//  {op index, value} on a side slot of the id that stayed, that entry writes the winner's value -- and reverted: with plain
+//  stores of the ids two entries of one key on different XCDs each read THEIR id back in the next kernel (conflicting
+//  plain stores to one word are not reconciled by a kernel boundary on this chip: two representatives per key, ~100
+//  wrong cells per 1.5 M-op Zipf batch, caught by tests/soak.py), and with agent-scope atomic stores the passes cost
+//  3.5 ms per 2^24 sets against 2.6 for the four below.  DESIGN.md "Measured and rejected".)
 
 // ---- directory growth -----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dir_rehash(const DirSlot* old, uint32_t old_size,

@@ -484,7 +484,6 @@ struct Matrix {
   bool no_ret = false;                  // the write batch in flight has no result array (d_out == NULL, CF import)
   uint32_t set_entries = 0;             // set batch in flight: entries of k_set_fold (0: the batch went op by op)
   DevBuf<uint32_t> ent_idx;
-  DevBuf<uint64_t> set_side;            // set batch: {op index, value} folded per key (k_set_rank_e2)
   DevBuf<uint32_t> big;                 // getrow: rows too large for one wave
   DevBuf<uint32_t> seg;                 // getrow: their segments (first segment per row, then a count per segment)
   uint32_t* d_small = nullptr;          // 16 words of scratch
@@ -1093,11 +1092,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // highest-index-wins across tiles, over the winners of k_set_fold only (locate also clears the value word)
     const uint32_t ne = m->set_entries;
     dim3 g(blocks_for(ne)), b(256);
-    m->set_side.need(ne);
-    unsigned long long* side = reinterpret_cast<unsigned long long*>(m->set_side.p);
-    hipLaunchKernelGGL(k_set_meet_e, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, ne, x, y, m->ent_idx.p, m->cellp.p, side, m->in_stride);
-    hipLaunchKernelGGL(k_set_rank_e2, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base, side, v, m->in_stride);
-    hipLaunchKernelGGL(k_set_store_e2, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base, side);
+    hipLaunchKernelGGL(k_set_locate_e, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, ne, x, y, m->ent_idx.p, m->cellp.p, m->in_stride);
+    hipLaunchKernelGGL(k_set_rank_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
+    hipLaunchKernelGGL(k_set_pick_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
+    hipLaunchKernelGGL(k_set_store_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, v, m->arena.base, m->in_stride);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(s));
   } else if (op == OP_SET) {
@@ -1368,7 +1366,7 @@ void smatrix_close(smatrix_t* self) {
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
-      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release(); m->set_side.release();
+      m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
       get_timing_resolve(m, 0);
       for (hipEvent_t e : m->ev_free) (void)hipEventDestroy(e);
       if (m->ev0) (void)hipEventDestroy(m->ev0);
