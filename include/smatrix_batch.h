@@ -141,6 +141,8 @@ typedef struct {
   uint64_t spec_chains;          /* write batches whose rounds 0 and 1 were enqueued at once, with one read-back (run_write) */
   uint64_t spec_refused;         /* of those: chains in which a growth task did not fit the estimates and was left to the host-driven loop */
   uint64_t file_bg_flushes;      /* of file_flushes: those the background flusher made (SMATRIX_FLUSH_MS, default 100; 0 = off) */
+  uint64_t cold_starts;          /* write batches whose large remainder was reduced to its distinct keys before the rounds went on (insert_pending_keys) */
+  uint64_t cold_keys;            /* distinct keys those inserted */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];

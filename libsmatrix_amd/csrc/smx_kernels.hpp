@@ -245,6 +245,25 @@ __device__ inline uint32_t* sub_ticket_elsewhere(SubCtr* subs, uint32_t k0) {
   return nullptr;
 }
 
+// `want` insert tickets at once (k_insert_keys: one request per row and workgroup), starting at share k0 and going round
+// all of them; returns how many it got.  Same invariant as sub_ticket: no share's count ever stays above its quota.
+__device__ inline uint32_t sub_tickets_bulk(SubCtr* subs, uint32_t k0, uint32_t want) {
+  if (__hip_atomic_load(&subs[0].pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;     // every share is used up
+  uint32_t got = 0;
+  for (uint32_t a = 0; a < SUBS && got < want; a++) {
+    SubCtr* sc = subs + ((k0 + a) & (SUBS - 1u));
+    const uint32_t cnt = __hip_atomic_load(&sc->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), quota = sc->quota;   // (quota is stable in op kernels)
+    if (cnt >= quota) continue;
+    const uint32_t take = min(want - got, quota - cnt);
+    const uint32_t old = atomicAdd(&sc->cnt, take);
+    const uint32_t ok = old >= quota ? 0u : min(take, quota - old);
+    if (ok < take) atomicSub(&sc->cnt, take - ok);
+    got += ok;
+  }
+  if (got == 0) __hip_atomic_store(&subs[0].pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (a full turn came up empty)
+  return got;
+}
+
 // ---- long probe sequences: the wave-cooperative window probe ---------------------------------------------
 // Row tables keep the reference's identity hash (y % size, src/smatrix.c:366) because their bytes are the file format.
 // With DENSE ids that hash clusters: low ids fill a contiguous run and every id that wraps onto the run walks to its
@@ -498,6 +517,170 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
   apply_body<OP>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+}
+
+// The keys of the listed ops -- DISTINCT keys (k_dedup_keys) -- inserted with value 0 where they do not exist (an incr by 0:
+// src/smatrix.c:236-243 on an absent key inserts {y, 0} and adds 0).  The list of a cold start names a few thousand rows
+// with up to 10^5 pending keys each, of which a row takes size/2 per round: with one `used` ticket attempt per key
+// (apply_row) the hottest row's word took 3 x 10^5 refused add/sub pairs per round, 1.2 ms per launch.  Here the lanes of
+// a workgroup that stand at an empty cell of the same row ask for their tickets TOGETHER: one add (and one give-back
+// of what was refused) per row and workgroup; a lane with a ticket keeps it until its key is in (nobody else inserts
+// that key).  Big rows (sub-counter quotas) and long probe sequences take the general path.
+constexpr uint32_t INS_THREADS = 1024;
+__global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t* defer, uint32_t st) {
+  __shared__ uint32_t l_row[2 * INS_THREADS], l_cnt[2 * INS_THREADS], l_grant[2 * INS_THREADS];
+  __shared__ uint32_t l_n, l_base;
+  for (uint64_t t064 = (uint64_t)blockIdx.x * INS_THREADS; t064 < n; t064 += (uint64_t)gridDim.x * INS_THREADS) {   // block-uniform
+    const uint32_t t = (uint32_t)t064 + threadIdx.x;
+    const bool live = t < n;
+    for (uint32_t i = threadIdx.x; i < 2 * INS_THREADS; i += INS_THREADS) { l_row[i] = 0xFFFFFFFFu; l_cnt[i] = 0; }
+    if (threadIdx.x == 0) l_n = 0;
+    uint32_t j = 0, Y = 0, pos = 0, mask = 0, e = 0, rank = 0;
+    bool deferred = false, need = false, general = false;
+    uint4 s = {0, 0, 0, 0};
+    DirSlot* d = nullptr;
+    uint64_t* cells = nullptr;
+    LongProbe lp{false, nullptr, 0, 0};
+    if (live) {
+      j = idx[t];
+      Y = ys[(size_t)j * st];
+      d = dir_find(dir, dmask, xs[(size_t)j * st], &s);
+      if (!d || s.z == 0) deferred = true;                       // the row does not exist (yet): prep creates it
+      else if (Y == 0) general = true;
+      else {
+        mask = (1u << meta_lg(s.x)) - 1u;
+        cells = row_cells(arena, s.z);
+        if (!(s.x & META_DIRTY)) d->meta = s.x | META_DIRTY;
+        pos = Y & mask;
+        for (uint32_t steps = 0;; steps++) {
+          const uint64_t c = cells[pos];
+          if (cell_key(c) == Y) break;                           // it exists: nothing to do
+          if (c == 0) { need = true; break; }
+          if (steps > PROBE_BUDGET) { general = true; break; }
+          pos = (pos + 1) & mask;
+        }
+        if (need && meta_lg(s.x) < BIG_LG && s.w > (mask + 1u) / 2u) { need = false; deferred = true; }     // (the snapshot already shows the row full)
+      }
+    }
+    __syncthreads();
+    // the tickets of this workgroup, one request per row
+    const uint32_t h = (uint32_t)(d - dir);
+    bool owner = false;
+    if (need) {
+      e = (h * 0x9E3779B1u) >> 21;                               // 11 bits
+      for (;;) {
+        const uint32_t prev = atomicCAS(&l_row[e], 0xFFFFFFFFu, h);
+        if (prev == 0xFFFFFFFFu) { owner = true; break; }
+        if (prev == h) break;
+        e = (e + 1) & (2 * INS_THREADS - 1);
+      }
+      rank = atomicAdd(&l_cnt[e], 1u);
+    }
+    __syncthreads();
+    if (owner) {
+      // a ticket is good while the count before it is <= size/2 (src/smatrix.c:346).  A coherent look first: once the row is
+      // full -- after the first few workgroups of a launch -- nobody has to add and take back any more
+      const uint32_t limit = (mask + 1u) / 2u, now = aload(&d->used);
+      uint32_t ok = 0;
+      if (meta_lg(s.x) >= BIG_LG) {
+        // big row: the room is shared out over its sub-counters (see SubCtr)
+        ok = sub_tickets_bulk(row_subs(arena, s.z, meta_lg(s.x)), (blockIdx.x * 5u + (e & 7u)) & (SUBS - 1u), l_cnt[e]);
+      } else if (now <= limit) {
+        const uint32_t want = min(l_cnt[e], limit + 1u - now);
+        const uint32_t base = atomicAdd(&d->used, want);
+        ok = base > limit ? 0u : min(want, limit + 1u - base);
+        if (ok < want) atomicSub(&d->used, want - ok);
+      }
+      l_grant[e] = ok;
+    }
+    __syncthreads();
+    if (need) {
+      if (rank >= l_grant[e]) deferred = true;
+      else {
+        // the ticket is this key's until it is in: a cell lost to another key only moves the walk on
+        for (uint32_t guard = 0; guard <= mask; guard++) {
+          const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull, (unsigned long long)pack_cell(Y, 0u));
+          if (prev == 0) break;
+          if (cell_key(prev) == Y) {                             // (not with distinct keys.  Big rows: `used` is the folded part of the
+            atomicSub(&d->used, 1u);                             //  count, rowlen = used + sum(cnt) stays exact this way too)
+            break;
+          }
+          do { pos = (pos + 1) & mask; } while (ld_relaxed(&cells[pos]) != 0 && cell_key(ld_relaxed(&cells[pos])) != Y && ++guard <= mask);
+        }
+      }
+    }
+    // the general path (big rows: sub-counter quotas; long probe sequences: the wave-cooperative probe)
+    uint32_t r = 0;
+    if (general) r = apply_row<OP_INCR, true, 1>(d, s, arena, Y, 0u, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp);
+    while (__any(lp.need)) {
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+      if (lp.need) {
+        lp.need = false;
+        if (p == PROBE_NONE) deferred = true;
+        else r = apply_row<OP_INCR, true, 1>(d, s, arena, Y, 0u, p, &deferred, &lp);
+      }
+    }
+    (void)r;
+    // what stays deferred: one list reservation per workgroup
+    const uint64_t dm = __ballot(deferred);
+    uint32_t wbase = 0;
+    if (dm && __lane_id() == 0) wbase = atomicAdd(&l_n, (uint32_t)__popcll(dm));
+    wbase = __shfl(wbase, 0);
+    __syncthreads();
+    if (threadIdx.x == 0 && l_n) l_base = atomicAdd(&ctl->n_defer, l_n);
+    __syncthreads();
+    if (deferred) defer[l_base + wbase + (uint32_t)__popcll(dm & ((1ull << __lane_id()) - 1ull))] = j;
+    __syncthreads();                                             // the LDS tables are reused by the next trip
+  }
+}
+
+// One representative op per distinct key (x, y != 0) among the listed ops: a scratch hash set of 64-bit keys (zeroed by the
+// caller, >= 2 slots per op), the first op to claim a key goes to `reps`.  Representatives are collected in LDS and leave
+// with ONE reservation per workgroup and DEDUP_TRIPS x 1024 ops (a reservation per wave queued 10^5 atomics on one word).
+constexpr uint32_t DEDUP_THREADS = 1024, DEDUP_TRIPS = 8;
+__global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs,
+                                                             const uint32_t* __restrict__ ys, uint32_t st, unsigned long long* set,
+                                                             uint64_t set_mask, uint32_t* reps, uint32_t* n_reps) {
+  __shared__ uint32_t l_rep[DEDUP_THREADS * DEDUP_TRIPS];
+  __shared__ uint32_t l_n, l_base;
+  for (uint64_t b0 = (uint64_t)blockIdx.x * DEDUP_THREADS * DEDUP_TRIPS; b0 < n; b0 += (uint64_t)gridDim.x * DEDUP_THREADS * DEDUP_TRIPS) {
+    if (threadIdx.x == 0) l_n = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k < DEDUP_TRIPS; k++) {
+      const uint64_t t = b0 + (uint64_t)k * DEDUP_THREADS + threadIdx.x;
+      bool won = false;
+      uint32_t j = 0;
+      if (t < n) {
+        j = idx[t];
+        const uint32_t X = xs[(size_t)j * st], Y = ys[(size_t)j * st];
+        if (Y != 0) {                                     // (y == 0 never inserts: quirk Q1)
+          const unsigned long long key = ((unsigned long long)X << 32) | Y;
+          uint64_t h = splitmix_at(0x5eedull, key) & set_mask;
+          for (;;) {
+            // (a plain look first: a hot key has 10^5 duplicates, and as many CAS on its slot queue at the memory side --
+            //  the kernel took 3 ms; a stale line can only show an empty slot, which the CAS then settles)
+            unsigned long long prev = set[h];
+            if (prev == 0ull) prev = atomicCAS(&set[h], 0ull, key);
+            if (prev == 0ull) { won = true; break; }
+            if (prev == key) break;
+            h = (h + 1) & set_mask;
+          }
+        }
+      }
+      const uint64_t wm = __ballot(won);
+      uint32_t wb = 0;
+      if (wm && __lane_id() == 0) wb = atomicAdd(&l_n, (uint32_t)__popcll(wm));
+      wb = __shfl(wb, 0);
+      if (won) l_rep[wb + (uint32_t)__popcll(wm & ((1ull << __lane_id()) - 1ull))] = j;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && l_n) l_base = atomicAdd(n_reps, l_n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < l_n; i += DEDUP_THREADS) reps[l_base + i] = l_rep[i];
+    __syncthreads();
+  }
 }
 
 // ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
@@ -835,7 +1018,9 @@ __device__ __forceinline__ void prep_body(
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
     FreeLists fl, uint32_t st, uint32_t create_only) {
-  // create_only: rows are created, nothing is flagged for growth (the bulk path decides growth itself, k_fix_rows)
+  // create_only bit 0: rows are created, nothing is flagged for growth (the bulk path decides growth itself, k_fix_rows)
+  //             bit 1: the listed ops' keys are known to be ABSENT (k_insert_keys has just looked: a key that exists is never
+  //                    deferred, and nobody inserts another list entry's key) -- step C's probe is skipped
   // block-scope scratch of the row-creation step
   __shared__ uint32_t l_set[2 * PREP_THREADS];     // row ids this block is creating (hash set, dedupe)
   __shared__ uint32_t l_cnt[4];                    // [0] lanes at an empty slot, [1] winners, [2] r0, [3] added
@@ -968,8 +1153,12 @@ __device__ __forceinline__ void prep_body(
     bool absent = false;
     uint32_t base = 0, lg = 0;
     LongProbe lp{false, nullptr, 0, 0};
-    if (create_only) continue;                      // (block-uniform)
-    if (live && !missing && Y != 0) {
+    if (create_only & 1u) continue;                 // (block-uniform)
+    if ((create_only & 2u) && live && !missing && Y != 0) {
+      base = dir[h].base;
+      lg = meta_lg((uint32_t)mx);
+      absent = base != 0;
+    } else if (live && !missing && Y != 0) {
       base = dir[h].base;          // plain: 0 only for a row created in this very launch
       if (base != 0) {
         lg = meta_lg((uint32_t)mx);

@@ -543,6 +543,11 @@ struct Matrix {
   uint32_t spec_nd_prev = 0, spec_nt_prev = 0, spec_nk_prev[4] = {0, 0, 0, 0};   // the previous batch's round 0: deferred ops, growth tasks (by kind)
   uint64_t spec_gu_prev = 0;            // ... and the units its growths took
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
+  // cold starts (insert_pending_keys): a large deferred list is reduced to its distinct keys once, and the rounds that the
+  // hot rows' doublings need run over those
+  uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
+  DevBuf<unsigned long long> cold_set;
+  DevBuf<uint32_t> cold_reps, cold_defer[2];
 };
 
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
@@ -897,6 +902,84 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
 // estimates is refused by k_grow_plan (its row stays as it is, its ops stay deferred), so whatever is left after the
 // chain -- refused tasks, rows that double twice in one batch, a full directory -- is finished by the host-driven loop
 // below exactly as before.  SMATRIX_SPEC=0 switches the chain off.
+// Cold start of hot rows.  A brand-new row that ends a batch at 2^k cells needs one round per doubling (the reference
+// doubles inline, src/smatrix.c:346-348 -- and every table between 16 and 2^k cells has to be filled to its threshold
+// and re-inserted in slot order for the final layout to be one the reference can produce), and every such round used
+// to re-run the op kernel over ALL ops still pending: the first batch of config 2 took 16 rounds of 1.9 ms over ~9 M
+// ops of which a few hundred thousand could insert.  Now a large deferred list is reduced ONCE to one representative
+// op per distinct key (k_dedup_keys), the rounds run over these with the lane-per-op kernel as inserts of {y, 0}
+// (k_insert_keys: an incr by 0) -- same prep, same growth passes, same thresholds -- and the caller's list then runs
+// once more over a table in which every key exists: all hits, with the real values and results.  That is the serial
+// order "first the inserting incr by 0 of every new key, then the batch's ops".
+// Returns false when the list is not worth it (few duplicates).
+bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const uint32_t* x, const uint32_t* y, hipStream_t s) {
+  // 1. distinct keys
+  uint64_t slots = 1;
+  while (slots < 2ull * n_list) slots <<= 1;
+  m->cold_set.need(slots);
+  m->cold_reps.need(n_list);
+  zero_async(m->cold_set.p, slots * 8, s);
+  HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 4, s));      // (words 0..9 of the scratch belong to the scalar path and the partition)
+  hipLaunchKernelGGL(k_dedup_keys, dim3(std::min<uint32_t>(blocks_for(n_list, DEDUP_THREADS * DEDUP_TRIPS), 4096)), dim3(DEDUP_THREADS), 0, s,
+                     n_list, list, x, y, m->in_stride, m->cold_set.p, slots - 1, m->cold_reps.p, m->d_small + 12);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  uint32_t cur_n = m->h_small[12];
+  if (m->trace_rounds)
+    fprintf(stderr, "[smatrix] batch %llu cold start: %u pending ops name %u distinct keys\n", (unsigned long long)m->st.batches, n_list, cur_n);
+  if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) return false;
+  m->st.cold_starts++;
+  m->st.cold_keys += cur_n;
+  // 2. the rounds, over the keys
+  const uint32_t* idx = m->cold_reps.p;
+  uint32_t stalled = 0, rows_before = m->dir_used;
+  for (uint32_t round = 0; cur_n; round++) {
+    if (stalled > 8) smx_die("write batch did not converge (corrupt row table?)");
+    const uint32_t dir_limit = m->dir_size / 2;
+    const uint32_t room = dir_limit > m->dir_used ? dir_limit - m->dir_used : 0;
+    m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
+    m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
+    m->klist.need(4 * (size_t)m->klist_cap);
+    m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
+    m->cold_defer[round & 1].need(cur_n);
+    uint32_t* dl = m->cold_defer[round & 1].p;
+    ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
+    ctl_reset_round(m, s);
+    hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base,
+                       cur_n, idx, x, y, dl, m->in_stride);
+    hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
+                       m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
+                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
+                       m->rebal.p, m->fl, m->in_stride, 2u);
+    HIP_OK(hipGetLastError());
+    ctl_read(m, s);
+    m->st.rounds++;
+    const Ctl& c = *m->h_ctl;
+    if (m->trace_rounds)
+      fprintf(stderr, "[smatrix] batch %llu cold round %u: keys=%u deferred=%u grow=%u (%llu units) rebal=%u dir_full=%u rows=%u\n",
+              (unsigned long long)m->st.batches, round, cur_n, c.n_defer, c.n_tasks, (unsigned long long)c.grow_units, c.n_rebal, c.dir_full, c.dir_used);
+    if (c.arena_oom) smx_die("internal: arena reservation too small");
+    const uint32_t nd = c.n_defer;
+    if (nd == 0) break;
+    const bool progress = nd < cur_n || c.n_tasks || c.n_rebal || c.dir_full || m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
+    stalled = progress ? 0 : stalled + 1;
+    rows_before = m->dir_used;
+    m->st.deferred_ops += nd;
+    if (c.n_tasks) grow_rows(m, s, c.n_tasks, c.grow_units, c.n_kind, false);
+    if (c.n_rebal) {
+      hipLaunchKernelGGL(k_rebal, dim3(std::min<uint32_t>(blocks_for(c.n_rebal, 64), 1024)), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
+      HIP_OK(hipGetLastError());
+      m->st.rows_rebalanced += c.n_rebal;
+    }
+    if (c.dir_full) grow_directory(m, 4, s);
+    else if ((uint64_t)m->dir_used * 2 >= m->dir_size) grow_directory(m, 2, s);
+    idx = dl;
+    cur_n = nd;
+  }
+  return true;
+}
+
 void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t* y,
                const uint32_t* v, uint32_t* out, hipStream_t s) {
   if (n == 0) return;
@@ -917,6 +1000,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   uint32_t stalled = 0, rows_before = m->dir_used;
   m->long_probes = false;
   uint32_t rounds_this_batch = 0;
+  bool cold_tried = false;
   // the chain is tried when the previous write batch was finished by its round 1 (or by the chain itself)
   bool chain = m->spec_enabled && m->spec_ready && !m->expect_bulk && n >= m->agg_min && m->dbg_after == 0;
   for (uint32_t round = 0;; round++) {
@@ -930,6 +1014,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
     m->klist.need(4 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
+    if (round >= 1 && idx && !cold_tried && m->cold_min && cur_n >= m->cold_min && (op == OP_INCR || op == OP_DECR) && !m->long_probes) {
+      // a large remainder after the first rounds: the cold start of hot rows (insert_pending_keys); afterwards this round
+      // runs over a table in which the keys of `idx` exist
+      cold_tried = true;
+      if (insert_pending_keys(m, idx, cur_n, x, y, s)) rounds_this_batch += 4;     // (not the steady shape: no chain for the next batch)
+    }
     uint32_t* dl = m->defer[round & 1].p;
     const bool chained = chain && round == 0;
     // estimates for the chain's growth round: four times what the previous batch needed (k_grow_plan refuses the rest)
@@ -1308,6 +1398,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_DBG_AFTER")) m->dbg_after = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SPEC")) m->spec_enabled = *a != '0';
+  if (const char* a = getenv("SMATRIX_COLD_MIN")) m->cold_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));

@@ -440,3 +440,41 @@ def test_set_batch_duplicates_across_many_tiles_zipf(G, oracle_mod):
             assert (a == v).all()                                   # set returns what it was given (:230)
         assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rep
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("shape", ["zipf", "one-giant-row", "dense"])
+def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
+    """A large remainder after the first rounds of a write batch (the cold start of hot rows: one round per doubling) is
+    reduced to one representative op per distinct key; the doubling rounds insert those keys with value 0 (an incr by 0,
+    src/smatrix.c:236-243) -- tickets asked for per row and workgroup, big rows through their sub-counters in bulk -- and
+    the batch's ops then run over a table in which every key exists.  Forced on small batches here (SMATRIX_COLD_MIN);
+    values, per-key return multisets, row sizes and rowlens are the oracle's.  one-giant-row: 60000 distinct keys with
+    duplicates into one new row (it ends at 2^17 cells: sub-counter quotas from 2^15 on).  dense: unscrambled ids (long
+    probe sequences take the general path)."""
+    monkeypatch.setenv("SMATRIX_COLD_MIN", "500")
+    rng = np.random.default_rng(1618)
+    g, o = G(), oracle_mod.Oracle()
+    for rnd in range(4):
+        n = 400000
+        if shape == "zipf":
+            x = (rng.zipf(1.2, n) % 3000).astype(np.uint32); y = (rng.zipf(1.15, n) % (1 << 20)).astype(np.uint32) + (rnd % 2)
+        elif shape == "one-giant-row":
+            x = np.where(rng.random(n) < 0.9, 7, rng.integers(0, 50, n)).astype(np.uint32)
+            y = (rng.integers(1, 60000 + 30000 * rnd, n)).astype(np.uint32) * 2654435761 % (1 << 31)
+            y = y.astype(np.uint32)
+        else:
+            x = (rng.zipf(1.2, n) % 200).astype(np.uint32); y = (rng.zipf(1.1, n) % 100000).astype(np.uint32)
+        v = ((x * 3 + y) % 5 + 1).astype(np.uint32)
+        op = 3 if rnd == 2 else 2
+        a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
+        k = x.astype(np.uint64) << 32 | y
+        assert (a[np.lexsort((a, k))] == b[np.lexsort((b, k))]).all(), rnd
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rnd
+    st = g.stats()
+    assert st["cold_starts"] >= 1 and st["cold_keys"] > 0, st
+    rows = o.list_rows()
+    assert st["rows"] == rows.size
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    for r in rows[:80].tolist() + [7]:
+        assert g.row_info(r) == o.row_info(r), r
+    g.close(); o.close()
