@@ -137,6 +137,11 @@ struct GrowTask {
   uint32_t chunk0;       // first 64-slot chunk of the old table in the flat chunk space
   uint32_t chunk0_new;   // same for the new table
   uint32_t dup;          // the old table holds one key twice (see grow_fixdup_one)
+  // chunked tasks, clustered rows (k_grow_move_home): cells of the old table's LAST run are not taken for at-home cells when
+  // the run goes on round the end of the table -- the wrapped cells come earlier in old slot order and may take their places
+  uint32_t wrap_from;    // the smallest old home among the wrapped cells of the table's first run (k_grow_map); none: 2^32-1
+  uint32_t wrap_seen;    // the same over ALL cells, as the first pass comes across them; smaller than wrap_from (a wrapped cell
+                         // behind a hole, quirk Q1/Q3) sends the row to the serial redo
 };
 
 // How a row is doubled: tables whose old cells and new slots fit in LDS are rebuilt there by one wave
@@ -1888,6 +1893,7 @@ __device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* task
       k.new_base = (uint32_t)u;
       k.count = 0;
       k.dup = 0;
+      k.wrap_from = k.wrap_seen = 0xFFFFFFFFu;
     }
     __syncthreads();
   }
@@ -1900,8 +1906,9 @@ __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, ui
 
 // chunk -> task maps, filled one wave per CHUNKED task (prep lists them: a steady batch has ~50 of them among 60 000
 // tasks, and a wave per task of ALL kinds made this trivial pass 40 us of the growth round's critical path)
-__device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const GrowTask* tasks, const uint32_t* list,
-                                              uint32_t* map_old, uint32_t* map_new) {
+// arena != nullptr (clustered rows, k_grow_move_home): GrowTask::wrap_from is worked out as well
+__device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
+                                              uint32_t* map_old, uint32_t* map_new, uint8_t* arena) {
   // one WORKGROUP per chunked task (a 2 M-slot row has 10^5 chunk entries: one wave writing them all was 30 us of the
   // growth round's critical path)
   const uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
@@ -1912,11 +1919,32 @@ __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, const Gro
     const uint32_t oc = 1u << (k.old_lg - 6), nc = 2u * oc;                          //  still mapped: the passes skip it by new_base)
     for (uint32_t c = threadIdx.x; c < oc; c += blockDim.x) map_old[k.chunk0 + c] = t;
     for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) map_new[k.chunk0_new + c] = t;
+    if (arena && k.new_base != 0) {
+      // GrowTask::wrap_from: the table's first run, window by window up to its first empty slot
+      __shared__ uint32_t l_wrap, l_end;
+      if (threadIdx.x == 0) { l_wrap = 0xFFFFFFFFu; l_end = 0xFFFFFFFFu; }
+      __syncthreads();
+      const uint64_t* O = row_cells(arena, k.old_base);
+      const uint32_t old_size = 1u << k.old_lg;
+      for (uint32_t b0 = 0; b0 < old_size; b0 += blockDim.x) {                 // block-uniform
+        const uint32_t p = b0 + threadIdx.x;
+        const uint64_t c = O[p];
+        if (c == 0) atomicMin(&l_end, p);
+        __syncthreads();
+        if (c != 0 && p < l_end && (cell_key(c) & (old_size - 1u)) > p) atomicMin(&l_wrap, cell_key(c) & (old_size - 1u));
+        const bool done = l_end != 0xFFFFFFFFu;                                   // (uniform: read between two barriers)
+        __syncthreads();
+        if (done) break;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) tasks[t].wrap_from = l_wrap;
+      __syncthreads();
+    }
   }
 }
-__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, const GrowTask* tasks, const uint32_t* list,
-                                                  uint32_t* map_old, uint32_t* map_new) {
-  grow_map_body(SMX_VG, ctl, tasks, list, map_old, map_new);
+__global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
+                                                  uint32_t* map_old, uint32_t* map_new, uint8_t* arena) {
+  grow_map_body(SMX_VG, ctl, tasks, list, map_old, map_new, arena);
 }
 
 // Rows whose old and new table fit in LDS are rebuilt there by one wave or one workgroup (the SCOPE).
@@ -2066,9 +2094,147 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
   grow_move_body(SMX_VG, ctl, tasks, map_old, arena);
 }
 
+// ---- clustered rows (dense ids): the chunked rehash in two passes with a bitmap of the cells that stay AT HOME ---------
+// With unscrambled ids a big row is one dense run: keys below the table size sit at home (identity hash), and every key
+// that wraps onto the run walks to its end -- 10^4..10^5 cells, one dependent load each, for thousands of cells per
+// doubling (k_grow_move took 19.6 ms of a 43 ms step).  Two facts about smatrix_rmap_resize's re-insertion in old slot
+// order (src/smatrix.c:392-404) make the walk cheap:
+//   (1) a cell never ends further from its new home than it was from its old one (the cells in front of it in old slot
+//       order that can reach its new probe sequence at all are the ones that sat between its old home and itself);
+//   (2) hence a cell that sat AT HOME in the old table (slot == key mod size) sits at home in the new one -- at slot p or
+//       p + size -- whatever the others do, and any cell whose walk comes across it has a LATER old slot (lower priority).
+// So pass 1 (k_grow_move_home) stores every at-home cell at its final place with a plain store and leaves, per 64 new
+// slots, the mask of the slots it filled: the two mask words of an old chunk are exactly new chunks c and c + size/64,
+// written whole by the one wave that owns the old chunk -- no atomics, no initialisation.  Pass 2 (k_grow_move_rest) moves
+// the displaced cells with the usual priority probing, but steps over at-home residents 64 at a time by the masks
+// without looking at them; k_grow_finish's duplicate check skips them the same way (an at-home resident's key is
+// congruent to its own slot, so beyond the first slot of a probe sequence it cannot be the key looked for).
+// Taken when a batch has shown long probe sequences (Matrix::clustered); scrambled ids keep the single pass.
+__device__ __forceinline__ void grow_move_home_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old,
+                                                    uint8_t* arena, unsigned long long* home_bits) {
+  const uint32_t nchunks = aload(&ctl->n_chunks);
+  const uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, nwaves = (g.nb * blockDim.x) >> 6;
+  for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
+    const uint32_t t = map_old[ch];
+    GrowTask& k = tasks[t];
+    if (k.new_base == 0) continue;                 // refused by the plan (wave-uniform)
+    const uint32_t old_size = 1u << k.old_lg, c = ch - k.chunk0, p = c * 64 + lane;
+    const uint64_t cur = row_cells(arena, k.old_base)[p];      // (chunked rows have >= 16384 cells: p < old_size)
+    const uint64_t m = __ballot(cur != 0);
+    if (lane == 0 && m) {
+      if (k.old_lg + 1 >= BIG_LG) atomicAdd(&row_subs(arena, k.new_base, k.old_lg + 1)[ch & (SUBS - 1u)].cnt, (uint32_t)__popcll(m));
+      else atomicAdd(&k.count, (uint32_t)__popcll(m));
+    }
+    const uint32_t key = cell_key(cur), h_old = key & (old_size - 1u);
+    if (cur != 0 && h_old > p) atomicMin(&k.wrap_seen, h_old);  // (a wrapped cell: a handful per table at most)
+    const bool home = cur != 0 && h_old == p && p < k.wrap_from;
+    const bool hi = home && (key & old_size);                   // new home = p + old_size
+    if (home) row_cells(arena, k.new_base)[hi ? p + old_size : p] = pack_cell(key, p + 1);     // {key, priority}, like a moving cell
+    const uint64_t lo_m = __ballot(home && !hi), hi_m = __ballot(hi);
+    if (lane == 0) {
+      home_bits[k.chunk0_new + c] = lo_m;
+      home_bits[k.chunk0_new + c + (old_size >> 6)] = hi_m;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_grow_move_home(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena,
+                                                        unsigned long long* home_bits) {
+  grow_move_home_body(SMX_VG, ctl, tasks, map_old, arena, home_bits);
+}
+
+// the first slot at/after i (cyclically) that no at-home cell holds; `bits` = the row's mask words
+__device__ inline uint32_t next_not_home(const unsigned long long* bits, uint32_t i, uint32_t nmask) {
+  for (uint32_t guard = 0; guard <= (nmask >> 6) + 1u; guard++) {
+    const unsigned long long free = ~bits[i >> 6] >> (i & 63u);       // bit 0 = slot i
+    if (free) {
+      const uint32_t adv = (uint32_t)__ffsll(free) - 1u;
+      if ((i & 63u) + adv < 64u) return i + adv;
+    }
+    i = ((i | 63u) + 1u) & nmask;                                     // nothing in this word: on to the next
+  }
+  return i;                                                           // (every slot at home: cannot be, load <= 1/2 + 1)
+}
+
+// the same as a walk that keeps the mask word it is in (successive slots of a walk mostly lie in one word)
+struct HomeWalk {
+  const unsigned long long* bits;
+  uint32_t nmask, widx;
+  unsigned long long word;
+  __device__ inline uint32_t next(uint32_t i) {
+    for (uint32_t guard = 0; guard <= (nmask >> 6) + 1u; guard++) {
+      if ((i >> 6) != widx) { widx = i >> 6; word = bits[widx]; }
+      const unsigned long long free = ~word >> (i & 63u);
+      if (free) return i + (uint32_t)__ffsll(free) - 1u;           // (bits beyond the word's end are zero after the shift)
+      i = ((i | 63u) + 1u) & nmask;
+    }
+    return i;
+  }
+};
+
+__device__ __forceinline__ void grow_move_rest_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old,
+                                                    uint8_t* arena, const unsigned long long* home_bits) {
+  const uint32_t nchunks = aload(&ctl->n_chunks);
+  const uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, nwaves = (g.nb * blockDim.x) >> 6;
+  for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
+    const uint32_t t = map_old[ch];
+    const GrowTask k = tasks[t];
+    if (k.new_base == 0) continue;
+    const uint32_t old_size = 1u << k.old_lg, p = (ch - k.chunk0) * 64 + lane;
+    uint64_t cur = row_cells(arena, k.old_base)[p];
+    if (k.wrap_seen < k.wrap_from && lane == 0) tasks[t].dup = 1;             // (see GrowTask::wrap_seen: redone serially at the commit)
+    if (cur == 0 || ((cell_key(cur) & (old_size - 1u)) == p && p < k.wrap_from)) continue;           // empty, or placed by the first pass
+    uint64_t* T = row_cells(arena, k.new_base);
+    const unsigned long long* bits = home_bits + k.chunk0_new;
+    const uint32_t nmask = (2u << k.old_lg) - 1u;
+    HomeWalk hw{bits, nmask, 0xFFFFFFFFu, 0ull};
+    uint32_t i = hw.next(cell_key(cur) & nmask);
+    cur = pack_cell(cell_key(cur), p + 1);          // {key, priority}
+    // The displaced cells of a dense row pile up behind its run of at-home cells, and a late one walks over all that
+    // came before it: the next MOVE_AHEAD slots of the walk are worked out from the masks and loaded TOGETHER.  A value
+    // read early is as good as one read in turn: a slot's resident only ever gives way to one of higher priority, so
+    // "came before me" stays true, and every claim or eviction is a compare-and-swap against what was read.
+    constexpr int MOVE_AHEAD = 8;
+    bool placed = false;
+    while (!placed) {
+      uint32_t at[MOVE_AHEAD];
+      uint64_t seen[MOVE_AHEAD];
+      at[0] = i;
+#pragma unroll
+      for (int b = 1; b < MOVE_AHEAD; b++) at[b] = hw.next((at[b - 1] + 1) & nmask);
+#pragma unroll
+      for (int b = 0; b < MOVE_AHEAD; b++) seen[b] = ld_relaxed(&T[at[b]]);
+#pragma unroll
+      for (int b = 0; b < MOVE_AHEAD; b++) {
+        if (placed) break;
+        uint64_t c = seen[b];
+        for (;;) {
+          if (c == 0) {
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&T[at[b]]), 0ull, (unsigned long long)cur);
+            if (prev == 0) { placed = true; break; }
+            c = prev;
+            continue;
+          }
+          if (cell_val(c) > cell_val(cur)) {             // resident came later in old order: evict it
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&T[at[b]]), (unsigned long long)c, (unsigned long long)cur);
+            if (prev != c) { c = prev; continue; }
+            cur = c;                                      // carry the evicted cell onward
+          }
+          break;
+        }
+      }
+      i = hw.next((at[MOVE_AHEAD - 1] + 1) & nmask);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_grow_move_rest(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena,
+                                                        const unsigned long long* home_bits) {
+  grow_move_rest_body(SMX_VG, ctl, tasks, map_old, arena, home_bits);
+}
+
 // one wave per 64 new slots: replace the carried old-slot index by the value
+// home_bits != nullptr: the two-pass move ran (clustered rows); the duplicate check steps over at-home residents
 __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTask* tasks,
-                                                 const uint32_t* map_new, uint8_t* arena) {
+                                                 const uint32_t* map_new, uint8_t* arena, const unsigned long long* home_bits = nullptr) {
   uint32_t nchunks = 2u * aload(&ctl->n_chunks);    // (chunked rows: the new table has twice the old one's chunks)
   uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
@@ -2088,15 +2254,38 @@ __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTa
         // a key that a probe from its home finds in ANOTHER slot first is a duplicate
         // (keys are stable during this kernel, only value words change)
         uint32_t nmask = new_size - 1u, i = cell_key(c) & nmask;
-        while (i != q && cell_key(T[i]) != cell_key(c)) i = (i + 1) & nmask;
+        if (home_bits) {
+          const unsigned long long* bits = home_bits + k.chunk0_new;
+          // (q itself is not at home unless q == i: the walk stops there at the latest)
+          if (i != q && cell_key(T[i]) != cell_key(c)) {
+            // (eight slots of the walk at a time, like k_grow_move_rest: keys do not change in this kernel)
+            HomeWalk hw{bits, nmask, 0xFFFFFFFFu, 0ull};
+            i = hw.next((i + 1) & nmask);
+            for (bool done = false; !done;) {
+              uint32_t at[8];
+              uint32_t kk[8];
+              at[0] = i;
+#pragma unroll
+              for (int b = 1; b < 8; b++) at[b] = at[b - 1] == q ? q : hw.next((at[b - 1] + 1) & nmask);
+#pragma unroll
+              for (int b = 0; b < 8; b++) kk[b] = cell_key(T[at[b]]);
+#pragma unroll
+              for (int b = 0; b < 8; b++)
+                if (!done && (at[b] == q || kk[b] == cell_key(c))) { done = true; i = at[b]; }
+              if (!done) i = hw.next((at[7] + 1) & nmask);
+            }
+          }
+        } else {
+          while (i != q && cell_key(T[i]) != cell_key(c)) i = (i + 1) & nmask;
+        }
         if (i != q) tasks[t].dup = 1;
       }
     }
   }
 }
 __global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* tasks,
-                                                     const uint32_t* map_new, uint8_t* arena) {
-  grow_finish_body(SMX_VG, ctl, tasks, map_new, arena);
+                                                     const uint32_t* map_new, uint8_t* arena, const unsigned long long* home_bits) {
+  grow_finish_body(SMX_VG, ctl, tasks, map_new, arena, home_bits);
 }
 
 // A row table can hold one key twice: y=0 writes may turn the uncounted (0,v) cell back

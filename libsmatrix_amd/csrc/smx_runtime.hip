@@ -545,6 +545,9 @@ struct Matrix {
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
   // cold starts (insert_pending_keys): a large deferred list is reduced to its distinct keys once, and the rounds that the
   // hot rows' doublings need run over those
+  // clustered rows: set for good once a batch has shown long probe sequences (dense ids); SMATRIX_CLUSTERED=1 / 0 forces it
+  bool clustered = false, clustered_forced = false;
+  DevBuf<unsigned long long> home_bits; // chunked growth in two passes: per 64 new slots, which of them hold cells that stayed at home
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
   DevBuf<unsigned long long> cold_set;
   DevBuf<uint32_t> cold_reps, cold_defer[2];
@@ -783,12 +786,27 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     sc = m->helper;
   }
   if (n_chunked) {
+    // clustered rows (a batch has shown long probe sequences: dense ids): the move in two passes, at-home cells first
+    // (smx_kernels.hpp "clustered rows")
+    const bool two_pass = m->clustered;
+    unsigned long long* bits = nullptr;
+    if (two_pass) {
+      m->home_bits.need(nc_bound + 1); bits = m->home_bits.p;
+    }
     hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 2048)),
-                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p);
-    hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p,
+                       two_pass ? m->arena.base : nullptr);
+    if (two_pass) {
+      hipLaunchKernelGGL(k_grow_move_home, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, bits);
+      hipLaunchKernelGGL(k_grow_move_rest, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, bits);
+    } else {
+      hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+    }
     hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
-                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base);
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base, bits);
     hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   }
@@ -1152,7 +1170,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       m->spec_nd_prev = cur_n;
     }
     if (nd == 0) break;
-    if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
+    if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; if (!m->clustered_forced) m->clustered = true; }
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
     stalled = progress ? 0 : stalled + 1;
@@ -1399,6 +1417,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SPEC")) m->spec_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_MIN")) m->cold_min = (uint32_t)strtoul(a, nullptr, 10);
+  if (const char* a = getenv("SMATRIX_CLUSTERED")) { m->clustered = *a != '0'; m->clustered_forced = true; }
   if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));

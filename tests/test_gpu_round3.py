@@ -478,3 +478,40 @@ def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
     for r in rows[:80].tolist() + [7]:
         assert g.row_info(r) == o.row_info(r), r
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("clustered", ["1", "0"])
+@pytest.mark.parametrize("shape", ["run-in-the-middle", "run-round-the-end"])
+def test_chunked_growth_of_a_clustered_row_is_the_reference_layout(G, oracle_mod, monkeypatch, shape, clustered):
+    """Dense ids: a 32768-cell row that is one long run of cells AT HOME plus keys that wrap onto the run, doubled by the
+    chunked rehash -- with SMATRIX_CLUSTERED=1 in two passes (at-home cells stored straight away, displaced cells step over
+    them by bit masks).  The table before the doubling is built so that its layout does not depend on the order inside a
+    batch (one batch of keys that all sit at home, then every colliding key in a call of its own), so the doubled table
+    must equal the reference's smatrix_rmap_resize byte for byte (src/smatrix.c:383-416).  run-round-the-end: the run
+    also covers the last slots of the table and goes on at slot 0 -- the wrapped cells come FIRST in old slot order and
+    take the places of cells that sat at home in the old table's last run."""
+    monkeypatch.setenv("SMATRIX_CLUSTERED", clustered)
+    S = 32768
+    g, o = G(), oracle_mod.Oracle()
+    if shape == "run-in-the-middle":
+        home = np.arange(1, 16001, dtype=np.uint32)                                    # slots 1..16000
+        extra = [S + 5 + 37 * i for i in range(150)] + [3 * S + 9000 + i for i in range(100)] + [5 * S + 1]
+    else:
+        home = np.concatenate([np.arange(1, 9001, dtype=np.uint32), np.arange(S - 7000, S, dtype=np.uint32)])
+        extra = [2 * S - 1 - i for i in range(60)] + [S + 3 + 11 * i for i in range(120)] + [3 * S - 2, 7 * S - 6999]
+    x = np.full(home.size, 9, np.uint32)
+    for m in (g, o):
+        m.apply(2, x, home, np.ones(home.size, np.uint32))
+    assert g.row_info(9) == o.row_info(9) and g.row_info(9)[0] == S
+    for y in extra:                                                                    # one call each: the order is the reference's
+        assert g.incr(9, y, 2) == o.incr(9, y, 2)
+    assert (np.asarray(g.row_slots(9)) == np.asarray(o.row_slots(9))).all()           # the table before the doubling
+    y = 9 * S + 100
+    while g.row_info(9)[0] == S:                                                       # single calls up to and over the threshold
+        assert g.incr(9, y, 1) == o.incr(9, y, 1)
+        y += 977
+    assert g.row_info(9) == o.row_info(9) and g.row_info(9)[0] == 2 * S
+    a, b = np.asarray(g.row_slots(9)), np.asarray(o.row_slots(9))
+    bad = np.flatnonzero((a != b).any(axis=1))
+    assert bad.size == 0, (bad[:10], a[bad[:10]], b[bad[:10]])
+    g.close(); o.close()
