@@ -457,7 +457,11 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
 #ifndef SMX_APPLY_SGPRS
 #define SMX_APPLY_SGPRS 80
 #endif
-template <int OP>
+// WPO (wave per op): lane 0 of every wave has an op, the other 63 only help with its long probe.  The retries of a
+// clustered table (dense ids) are short lists in which nearly every op walks 10^3..10^5 cells; lane per op, a wave then
+// takes its 64 long probes one after the other while most of the chip has nothing to do -- the second retry of a dense
+// batch took 4 ms for 4 500 ops.
+template <int OP, bool WPO = false>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -468,10 +472,11 @@ __device__ __forceinline__ void apply_body(
   if (n == 0xFFFFFFFFu) n = aload(&ctl->n_prev);
   // (64-bit trip counter: with n > 2^31 ops and a grid that covers them all, t0 + the grid's size wraps around in 32 bits
   //  and the ops at the front would be applied a SECOND time -- round 3, found by the 2^31 + 2^27-op batch test)
-  for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
-    const uint32_t t0 = (uint32_t)t064;
-    const uint32_t t = t0 + threadIdx.x;
-    const bool live = t < n;
+  const uint64_t n_lanes = WPO ? (uint64_t)n * 64u : (uint64_t)n;
+  for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n_lanes; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
+    const uint64_t tl = t064 + threadIdx.x;
+    const uint32_t t = WPO ? (uint32_t)(tl >> 6) : (uint32_t)tl;
+    const bool live = tl < n_lanes && (!WPO || (tl & 63u) == 0);
     uint32_t j = 0, r = 0, Y = 0, V = 0;
     bool deferred = false;
     LongProbe lp{false, nullptr, 0, 0};
@@ -686,6 +691,14 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
     for (uint32_t i = threadIdx.x; i < l_n; i += DEDUP_THREADS) reps[l_base + i] = l_rep[i];
     __syncthreads();
   }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS))) void k_apply_wpo(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
+  apply_body<OP, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 // ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
@@ -2142,20 +2155,8 @@ __global__ __launch_bounds__(256) void k_grow_move_home(const Ctl* ctl, GrowTask
   grow_move_home_body(SMX_VG, ctl, tasks, map_old, arena, home_bits);
 }
 
-// the first slot at/after i (cyclically) that no at-home cell holds; `bits` = the row's mask words
-__device__ inline uint32_t next_not_home(const unsigned long long* bits, uint32_t i, uint32_t nmask) {
-  for (uint32_t guard = 0; guard <= (nmask >> 6) + 1u; guard++) {
-    const unsigned long long free = ~bits[i >> 6] >> (i & 63u);       // bit 0 = slot i
-    if (free) {
-      const uint32_t adv = (uint32_t)__ffsll(free) - 1u;
-      if ((i & 63u) + adv < 64u) return i + adv;
-    }
-    i = ((i | 63u) + 1u) & nmask;                                     // nothing in this word: on to the next
-  }
-  return i;                                                           // (every slot at home: cannot be, load <= 1/2 + 1)
-}
-
-// the same as a walk that keeps the mask word it is in (successive slots of a walk mostly lie in one word)
+// the first slot at/after i (cyclically) that no at-home cell holds (`bits`: the row's mask words), as a walk that keeps
+// the mask word it is in: successive slots of a walk mostly lie in one word
 struct HomeWalk {
   const unsigned long long* bits;
   uint32_t nmask, widx;

@@ -547,6 +547,7 @@ struct Matrix {
   // hot rows' doublings need run over those
   // clustered rows: set for good once a batch has shown long probe sequences (dense ids); SMATRIX_CLUSTERED=1 / 0 forces it
   bool clustered = false, clustered_forced = false;
+  uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   DevBuf<unsigned long long> home_bits; // chunked growth in two passes: per 64 new slots, which of them hold cells that stayed at home
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
   DevBuf<unsigned long long> cold_set;
@@ -646,6 +647,13 @@ void grow_directory(Matrix* m, uint32_t factor, hipStream_t s) {
 template <int OP>
 void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                   const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
+  if (OP != OP_GET && idx && m->clustered && n <= m->wpo_max) {
+    // a retry list of a clustered table: a wave per op (k_apply_wpo)
+    hipLaunchKernelGGL((k_apply_wpo<OP>), dim3(std::min<uint32_t>(blocks_for((uint64_t)n * 64), 65536)), dim3(256), 0, s, m->d_ctl, m->d_dir,
+                       m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
+    HIP_OK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL((k_apply<OP>), dim3(blocks_for(n)), dim3(256), 0, s, m->d_ctl, m->d_dir,
                      m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
   HIP_OK(hipGetLastError());
@@ -1095,6 +1103,21 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
                          (uint64_t)(m->arena.mapped / UNIT_BYTES), list, x, y, m->tasks.p, m->klist.p, m->klist_cap,
                          m->rebal.p, m->fl, m->in_stride, 0u);
     };
+    // Clustered tables (dense ids): the folding kernel sets every op aside whose probe outruns its budget -- 770 000 of a
+    // 2^24-op batch of the dense stream, nearly all of them HITS on keys that sit far from home -- and prep then walked
+    // each of those probes to the end only to find the key present.  In the chained shape the whole deferred list takes
+    // a wave-per-op pass first (k_apply_wpo); prep, the growth round and the retry see what that pass leaves: the ops
+    // that really wait for a structure change.
+    const bool pre_pass = chained && m->clustered && (op == OP_INCR || op == OP_DECR);
+    if (pre_pass) {
+      uint32_t* dlp = m->defer[1].p;
+      hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
+      const dim3 wgrid(65536);
+      if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+      else hipLaunchKernelGGL((k_apply_wpo<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+      HIP_OK(hipGetLastError());
+      dl = dlp;
+    }
     launch_prep(dl);
     HIP_OK(hipGetLastError());
     DBG_STEP(m, s, "k_prep");
@@ -1109,8 +1132,16 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
       // the retry: lane per op over the device-side list (its length is ctl->n_prev), grid for 4x the previous batch's
       const uint32_t est_nd = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n);
-      uint32_t* dl1 = m->defer[1].p;
+      uint32_t* dl1 = pre_pass ? m->defer[0].p : m->defer[1].p;       // (the list the retry reads sits in the other one)
       const dim3 rgrid(std::min<uint32_t>(blocks_for(est_nd), 16384));
+      if (m->clustered && est_nd <= m->wpo_max) {
+        const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * 64), 65536));      // (a wave per op: launch_apply)
+        switch (op) {
+          case OP_SET:  hipLaunchKernelGGL((k_apply_wpo<OP_SET>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+          case OP_INCR: hipLaunchKernelGGL((k_apply_wpo<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+          default:      hipLaunchKernelGGL((k_apply_wpo<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+        }
+      } else
       switch (op) {
         case OP_SET:  hipLaunchKernelGGL((k_apply<OP_SET>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
         case OP_INCR: hipLaunchKernelGGL((k_apply<OP_INCR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
@@ -1150,7 +1181,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
                 c.spec_failed, c.n_defer, c.n_tasks, c.dir_used);
       if (nd_chain0 == 0) break;                               // round 0 deferred nothing: the rest of the chain ran empty
       cur_n = nd_chain0;
-      round = 1;
+      round = pre_pass ? 2 : 1;                                // (the next round writes the list that `dl` is NOT)
     } else if (m->trace_rounds) {
       static thread_local double t_prev = 0;
       struct timespec ts;
@@ -1418,6 +1449,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_SPEC")) m->spec_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_MIN")) m->cold_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_CLUSTERED")) { m->clustered = *a != '0'; m->clustered_forced = true; }
+  if (const char* a = getenv("SMATRIX_WPO_MAX")) m->wpo_max = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));

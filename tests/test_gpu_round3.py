@@ -384,14 +384,19 @@ def test_scalar_mirror_lock_free_under_threads(G, monkeypatch, cap):
     g.close()
 
 
-@pytest.mark.parametrize("tiny", [False, True])
+@pytest.mark.parametrize("tiny", [False, True, "clustered"])
 def test_speculative_chain_and_its_refusals(G, oracle_mod, monkeypatch, tiny):
     """run_write enqueues rounds 0 and 1 of a steady-state batch at once (op kernel, prep, growth passes sized from the
     previous batch, the retry over the device-side list, prep) and reads back once.  tiny: the estimates are forced far
     too small (5 growth tasks, 24 arena units), so that on every chained batch k_grow_plan REFUSES most rows -- they keep
     their tables, their ops stay deferred -- and the host-driven loop finishes the batch.  Either way values, per-key
     return multisets, row sizes and rowlens are the oracle's; directory growth and brand-new rows in the middle of it."""
-    if tiny:
+    if tiny == "clustered":
+        # the chain of a clustered table (dense ids), forced on: the whole deferred list takes a wave-per-op pass before prep
+        # (k_apply_wpo), the retries run a wave per op, large rows are doubled in two passes over the at-home bitmap
+        monkeypatch.setenv("SMATRIX_CLUSTERED", "1")
+        tiny = False
+    elif tiny:
         monkeypatch.setenv("SMATRIX_SPEC_TINY", "1")
     rng = np.random.default_rng(314)
     g, o = G(), oracle_mod.Oracle()
