@@ -143,6 +143,8 @@ typedef struct {
   uint64_t file_bg_flushes;      /* of file_flushes: those the background flusher made (SMATRIX_FLUSH_MS, default 100; 0 = off) */
   uint64_t cold_starts;          /* write batches whose large remainder was reduced to its distinct keys before the rounds went on (insert_pending_keys) */
   uint64_t cold_keys;            /* distinct keys those inserted */
+  uint64_t clustered_mode;       /* 1 once a write batch had >= 1/64 of its ops finished by the wave-cooperative probe (unscrambled ids: long runs
+                                    under the reference's identity hash): large rows are then doubled in two passes, retry lists run a wave per op */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];

@@ -104,7 +104,9 @@ struct Ctl {
   uint32_t n_rebal;      // big rows whose sub-counter quotas want re-partitioning
   uint32_t n_kind[4];    // growth tasks by kind (grow_kind): LDS by wave / workgroup / large workgroup, chunked
   uint32_t n_long;       // the folding kernel deferred ops whose probe outran its budget (the lane-per-op kernel takes them)
-  uint32_t pad0[2];
+  uint32_t n_long_ops;   // ... how many ops the lane-per-op WRITE kernel finished through the wave-cooperative probe in this round: a few on
+                         // any large table at load 1/2, percents of a batch on a clustered one (dense ids) -- Matrix::clustered
+  uint32_t pad0;
   // ---- persistent ----
   uint32_t dir_used;     // rows in the directory
   uint32_t pad1;
@@ -490,6 +492,10 @@ __device__ __forceinline__ void apply_body(
       d = dir_find(dir, dmask, xs[at], &s);
       if (!d || s.z == 0) deferred = (OP != OP_GET);      // get on an absent row: 0, creates nothing (S1)
       else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp);
+    }
+    if (OP != OP_GET && !WPO) {                           // (the host's evidence for "this table is clustered")
+      const uint64_t lm = __ballot(lp.need);
+      if (lm && __lane_id() == 0) atomicAdd(&ctl->n_long_ops, (uint32_t)__popcll(lm));
     }
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
       const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);

@@ -1201,7 +1201,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       m->spec_nd_prev = cur_n;
     }
     if (nd == 0) break;
-    if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; if (!m->clustered_forced) m->clustered = true; }
+    if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
+    // clustered: percents of a batch needed the wave-cooperative probe (dense ids: 4-5 %; any large table at load 1/2 has a few
+    // sequences beyond the budget -- the first batches of the scrambled stream do -- and must not switch it on)
+    if (!m->clustered_forced && !m->clustered && (uint64_t)m->h_ctl->n_long_ops * 64 >= n) m->clustered = true;
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
     stalled = progress ? 0 : stalled + 1;
@@ -2079,6 +2082,7 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   m->st.scalar_cache_flushes = m->cache.flushes.load();
   m->st.scalar_cache_flushed_cells = m->cache.flushed_cells.load();
   m->st.file_leaked_bytes = m->file_index ? file_leaked(m) : 0;
+  m->st.clustered_mode = m->clustered ? 1 : 0;
   *out = m->st;
 }
 

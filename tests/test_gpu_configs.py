@@ -90,6 +90,9 @@ def test_config2_reference_checksums_4e8():
     assert res["matches_reference"]
     assert res["at_4e8_ops"] == {"rows": 1000000, "nnz": 100401767, "max_rowlen": 935410}
     assert res["at_1e7_ops"]["sum_get"] == 52480898544
+    # the handful of probe sequences beyond the folding kernel's budget that any 10^5-cell table at load 1/2 has must not
+    # be taken for a clustered (dense-id) table: that mode runs a wave per deferred op (round 3: it was, 2.5 -> 3.7 ms per step)
+    assert res["clustered_mode"] == 0
     g = res["getrow_all_rows_at_4e8"]                  # one getrow call over all rows, the 2 M-slot row in 64 segments
     assert g["pairs"] == 100401767 and g["sum_of_values"] == 400000000 and g["max_row_pairs"] == 935410
     assert g["counts_equal_rowlen"]

@@ -349,6 +349,7 @@ def test_dense_ids_cooperative_probe_all_ops(G, oracle_mod):
             assert (a == b).all()
         assert (g.apply(0, xs, ys) == o.apply(0, xs, ys)).all(), rnd
     assert g.stats()["long_probe_rounds"] > 0           # the folding kernel did hand ops over
+    assert g.stats()["clustered_mode"] == 1             # ... so many that the table counts as clustered (wave per op, two-pass move)
     # ids far outside the table wrap onto the dense run: absent keys (get must walk the whole run), then inserts
     far = (np.arange(1, 5001, dtype=np.uint32) * 131072 + rng.integers(1, 200, 5000).astype(np.uint32))
     xr = rng.integers(0, 40, 5000, dtype=np.uint32)
