@@ -457,6 +457,7 @@ def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
     duplicates into one new row (it ends at 2^17 cells: sub-counter quotas from 2^15 on).  dense: unscrambled ids (long
     probe sequences take the general path)."""
     monkeypatch.setenv("SMATRIX_COLD_MIN", "500")
+    monkeypatch.setenv("SMATRIX_COLD_SHARE", "1000000000")       # whatever share of the batch is pending
     rng = np.random.default_rng(1618)
     g, o = G(), oracle_mod.Oracle()
     for rnd in range(4):
