@@ -471,7 +471,10 @@ def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
         else:
             x = (rng.zipf(1.2, n) % 200).astype(np.uint32); y = (rng.zipf(1.1, n) % 100000).astype(np.uint32)
         v = ((x * 3 + y) % 5 + 1).astype(np.uint32)
-        op = 3 if rnd == 2 else 2
+        op = 3 if rnd == 2 else 1 if rnd == 3 else 2
+        if op == 1:                                                  # a set batch with new keys: the highest index wins (src/smatrix.c:230 in call order)
+            y = (y + 7).astype(np.uint32)
+            v = rng.integers(1, 1 << 30, n, dtype=np.uint32)
         a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
         k = x.astype(np.uint64) << 32 | y
         assert (a[np.lexsort((a, k))] == b[np.lexsort((b, k))]).all(), rnd
