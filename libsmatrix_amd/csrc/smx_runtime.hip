@@ -799,6 +799,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   if (n_chunked) {
     // clustered rows (a batch has shown long probe sequences: dense ids): the move in two passes, at-home cells first
     // (smx_kernels.hpp "clustered rows")
+    // (scrambled ids, same box, A/B: the two passes cost 2.475 / 2.487 ms per step against 2.447 / 2.442 for the single one)
     const bool two_pass = m->clustered;
     unsigned long long* bits = nullptr;
     if (two_pass) {
