@@ -524,3 +524,41 @@ def test_chunked_growth_of_a_clustered_row_is_the_reference_layout(G, oracle_mod
     bad = np.flatnonzero((a != b).any(axis=1))
     assert bad.size == 0, (bad[:10], a[bad[:10]], b[bad[:10]])
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("clustered", ["1", "0"])
+def test_chunked_growth_after_one_call_per_key_is_the_reference_layout(G, oracle_mod, monkeypatch, clustered):
+    """The chunked rehash (rows of 16384 cells and more) on a table built ONE CALL PER KEY, so that every intermediate
+    layout is the reference's: a random mixture of dense low keys, keys that wrap onto them, keys around multiples of the
+    table size (runs that cross the end of the table) and far keys -- 16 500 keys take the row through the doublings
+    16384 -> 32768 -> 65536.  After every doubling the whole table must equal smatrix_rmap_resize's output slot by slot
+    (src/smatrix.c:383-416), with the single-pass move and with the two-pass move of clustered rows forced on."""
+    monkeypatch.setenv("SMATRIX_CLUSTERED", clustered)
+    rng = np.random.default_rng(20261003)
+    g, o = G(), oracle_mod.Oracle()
+    pool = np.concatenate([
+        rng.permutation(12000)[:7000] + 1,                                    # dense low ids, with holes
+        rng.integers(1, 1 << 31, 3000),                                       # far keys: wrap anywhere
+        (rng.integers(1, 9, 3000) << 14) + rng.integers(0, 3000, 3000),       # multiples of 16384 + small: wrap onto the dense ids
+        (rng.integers(1, 5, 2500) << 15) - rng.integers(1, 400, 2500),        # just below multiples of 32768: runs round the table's end
+        rng.integers(12000, 40000, 3000),                                     # the sparse middle
+    ]).astype(np.uint32)
+    pool = pool[np.sort(np.unique(pool, return_index=True)[1])]               # first occurrences, order kept
+    rng.shuffle(pool)
+    checked = []
+    size = 16
+    assert pool.size >= 16500
+    for y in pool[:16500].tolist():
+        assert g.incr(3, y, 1) == o.incr(3, y, 1)
+        s2 = g.row_info(3)[0]
+        if s2 != size:
+            size = s2
+            if size >= 32768:                                                 # a chunked doubling has just happened
+                a, b = np.asarray(g.row_slots(3)), np.asarray(o.row_slots(3))
+                bad = np.flatnonzero((a != b).any(axis=1))
+                assert bad.size == 0, (size, bad[:10], a[bad[:10]], b[bad[:10]])
+                checked.append(size)
+    assert g.row_info(3) == o.row_info(3)
+    assert checked == [32768, 65536], checked
+    assert (np.asarray(g.row_slots(3)) == np.asarray(o.row_slots(3))).all()
+    g.close(); o.close()
