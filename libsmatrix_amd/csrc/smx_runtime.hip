@@ -1045,7 +1045,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     m->klist.need(4 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
     if (round >= 1 && idx && !cold_tried && m->cold_min && cur_n >= m->cold_min && (uint64_t)cur_n * m->cold_share >= n &&
-        op != OP_GET && !m->long_probes) {
+        op != OP_GET) {
       // a large remainder after the first rounds: the cold start of hot rows (insert_pending_keys); afterwards this round
       // runs over a table in which the keys of `idx` exist
       cold_tried = true;
