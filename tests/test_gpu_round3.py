@@ -447,7 +447,7 @@ def test_set_batch_duplicates_across_many_tiles_zipf(G, oracle_mod):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("shape", ["zipf", "one-giant-row", "dense"])
+@pytest.mark.parametrize("shape", ["zipf", "one-giant-row", "dense", "many-new-rows"])
 def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
     """A large remainder after the first rounds of a write batch (the cold start of hot rows: one round per doubling) is
     reduced to one representative op per distinct key; the doubling rounds insert those keys with value 0 (an incr by 0,
@@ -455,8 +455,11 @@ def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
     the batch's ops then run over a table in which every key exists.  Forced on small batches here (SMATRIX_COLD_MIN);
     values, per-key return multisets, row sizes and rowlens are the oracle's.  one-giant-row: 60000 distinct keys with
     duplicates into one new row (it ends at 2^17 cells: sub-counter quotas from 2^15 on).  dense: unscrambled ids (long
-    probe sequences take the general path)."""
+    probe sequences take the general path).  many-new-rows: the bulk path switched off, 40 000 rows per batch that do not exist
+    yet -- the key rounds create them and rebuild the directory (65 536 slots at open) on the way."""
     monkeypatch.setenv("SMATRIX_COLD_MIN", "500")
+    if shape == "many-new-rows":
+        monkeypatch.setenv("SMATRIX_BULK", "0")
     monkeypatch.setenv("SMATRIX_COLD_SHARE", "1000000000")       # whatever share of the batch is pending
     rng = np.random.default_rng(1618)
     g, o = G(), oracle_mod.Oracle()
@@ -468,6 +471,8 @@ def test_cold_start_runs_over_distinct_keys(G, oracle_mod, monkeypatch, shape):
             x = np.where(rng.random(n) < 0.9, 7, rng.integers(0, 50, n)).astype(np.uint32)
             y = (rng.integers(1, 60000 + 30000 * rnd, n)).astype(np.uint32) * 2654435761 % (1 << 31)
             y = y.astype(np.uint32)
+        elif shape == "many-new-rows":
+            x = (rng.integers(0, 40000, n) + 40000 * rnd).astype(np.uint32); y = (rng.zipf(1.3, n) % 4).astype(np.uint32) + 1
         else:
             x = (rng.zipf(1.2, n) % 200).astype(np.uint32); y = (rng.zipf(1.1, n) % 100000).astype(np.uint32)
         v = ((x * 3 + y) % 5 + 1).astype(np.uint32)
