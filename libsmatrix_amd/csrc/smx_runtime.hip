@@ -958,7 +958,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   uint32_t cur_n = m->h_small[12];
   if (m->trace_rounds)
     fprintf(stderr, "[smatrix] batch %llu cold start: %u pending ops name %u distinct keys\n", (unsigned long long)m->st.batches, n_list, cur_n);
-  if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) return false;
+  if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) { m->cold_set.release(); m->cold_reps.release(); return false; }
   m->st.cold_starts++;
   m->st.cold_keys += cur_n;
   // 2. the rounds, over the keys
@@ -1007,6 +1007,9 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     idx = dl;
     cur_n = nd;
   }
+  // (a cold start happens once in a matrix's life: its scratch -- 256 MB for the first batch of config 2 -- goes back)
+  HIP_OK(hipStreamSynchronize(s));
+  m->cold_set.release(); m->cold_reps.release(); m->cold_defer[0].release(); m->cold_defer[1].release();
   return true;
 }
 
