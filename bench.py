@@ -102,13 +102,14 @@ def cpu_baseline(sample_ops, torch, dev):
         res["threads_8"] = {"value": round(2 * n8 / t8 / 1e6, 3), "unit": "Mops/s", "cores": T,
                             "sample": "first %d ops, each batch split over 8 threads: %.2fs" % (n8, t8)}
         # T = all physical cores.  The reference's spin locks scale NEGATIVELY under Zipf (one global
-        # reader count + per-row mutexes, src/smatrix.c:843-889), so the sample is kept small: 2^21 ops
+        # reader count + per-row mutexes, src/smatrix.c:843-889), so the sample is kept small: 2^20 ops (round 3; 2^21 took
+        # 18.5 s and pushed the whole CPU leg to 44 s)
         try:
             import psutil
             T = psutil.cpu_count(logical=False) or os.cpu_count()
         except Exception:
             T = os.cpu_count()
-        nall = min(sample_ops, 1 << 21)
+        nall = min(sample_ops, 1 << 20)
         m = O.Reference()
         xs, ys = x[:nall], y[:nall]
         ones = np.ones(nall, np.uint32)
