@@ -497,6 +497,8 @@ __device__ __forceinline__ void apply_body(
       const uint64_t lm = __ballot(lp.need);
       if (lm && __lane_id() == 0) atomicAdd(&ctl->n_long_ops, (uint32_t)__popcll(lm));
     }
+    // (a wave per op: one op in 64 is looked at, and counts for 64 -- the evidence for "not clustered any more")
+    if (OP != OP_GET && WPO && live && (t & 63u) == 0 && lp.need) atomicAdd(&ctl->n_long_ops, 64u);
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
       const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
       if (lp.need) {
@@ -2431,10 +2433,11 @@ __global__ void k_round_advance(Ctl* ctl, const uint32_t* rebal, DirSlot* dir, u
   ctl->spec_nrebal0 = ctl->n_rebal;
   ctl->spec_dirfull0 = ctl->dir_full;
   for (int k = 0; k < 4; k++) ctl->spec_nkind0[k] = ctl->n_kind[k];
-  const uint32_t keep_long = ctl->n_long, keep_oom = ctl->arena_oom;
+  const uint32_t keep_long = ctl->n_long, keep_oom = ctl->arena_oom, keep_long_ops = ctl->n_long_ops;
   uint64_t* z = reinterpret_cast<uint64_t*>(ctl);
   for (uint32_t i = 0; i < CTL_ROUND_BYTES / 8; i++) z[i] = 0;
   ctl->n_long = keep_long;                           // (sticky for the batch: the host switches the retries to lane-per-op)
+  ctl->n_long_ops = keep_long_ops;                   // (summed over the rounds of a chain)
   ctl->arena_oom = keep_oom;
 }
 

@@ -547,6 +547,7 @@ struct Matrix {
   // hot rows' doublings need run over those
   // clustered rows: set for good once a batch has shown long probe sequences (dense ids); SMATRIX_CLUSTERED=1 / 0 forces it
   bool clustered = false, clustered_forced = false;
+  uint32_t clustered_quiet = 0;         // chained batches in a row whose (sampled) count of long probes stayed below 1/256 of the batch
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   DevBuf<unsigned long long> home_bits; // chunked growth in two passes: per 64 new slots, which of them hold cells that stayed at home
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
@@ -1187,6 +1188,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         fprintf(stderr, "[smatrix] batch %llu chain: ops=%u deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u\n",
                 (unsigned long long)m->st.batches, cur_n, nd_chain0, c.spec_nt0, (unsigned long long)c.spec_gu0, c.spec_nrebal0,
                 c.spec_failed, c.n_defer, c.n_tasks, c.dir_used);
+      // clustered mode goes off again after 8 chained batches in a row with hardly a long probe (the ids have changed their
+      // nature: the wave-per-op pass in front of prep costs a scrambled-id batch 1.2 ms)
+      if (!m->clustered_forced && m->clustered) {
+        m->clustered_quiet = (uint64_t)c.n_long_ops * 256 < n ? m->clustered_quiet + 1 : 0;
+        if (m->clustered_quiet >= 8) m->clustered = false;
+      }
       if (nd_chain0 == 0) break;                               // round 0 deferred nothing: the rest of the chain ran empty
       cur_n = nd_chain0;
       round = pre_pass ? 2 : 1;                                // (the next round writes the list that `dl` is NOT)
@@ -1212,7 +1219,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
     // clustered: percents of a batch needed the wave-cooperative probe (dense ids: 4-5 %; any large table at load 1/2 has a few
     // sequences beyond the budget -- the first batches of the scrambled stream do -- and must not switch it on)
-    if (!m->clustered_forced && !m->clustered && (uint64_t)m->h_ctl->n_long_ops * 64 >= n) m->clustered = true;
+    if (!m->clustered_forced && !m->clustered && (uint64_t)m->h_ctl->n_long_ops * 64 >= n) { m->clustered = true; m->clustered_quiet = 0; }
+
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
     stalled = progress ? 0 : stalled + 1;

@@ -567,3 +567,35 @@ def test_chunked_growth_after_one_call_per_key_is_the_reference_layout(G, oracle
     assert checked == [32768, 65536], checked
     assert (np.asarray(g.row_slots(3)) == np.asarray(o.row_slots(3))).all()
     g.close(); o.close()
+
+
+def test_clustered_mode_comes_and_goes(G, oracle_mod):
+    """The clustered-table paths (a wave per op for retry lists and for the whole deferred list in front of prep, two-pass
+    move of large rows) are switched on by a write batch with >= 1/64 of its ops finished through the wave-cooperative probe
+    (dense ids) and off again after eight chained batches in a row with hardly any (the wave-per-op kernels look at one op
+    in 64) -- a matrix that once saw dense ids must not run scrambled-id batches at 2/3 of their speed for ever.  Values
+    stay the oracle's through both switches."""
+    from libsmatrix_amd import Stream
+    gen = Stream("zipf", 77, 300000, 1.1, 0)
+    g, o = G(), oracle_mod.Oracle()
+    rng = np.random.default_rng(8)
+    n = 200000
+    x, y = gen.fill(0, 4 * n)
+    x = (x % 40).astype(np.uint32)                                     # few rows -> large clustered tables
+    for k in range(4):
+        xs, ys = x[k * n:(k + 1) * n], y[k * n:(k + 1) * n]
+        v = ((xs + ys) % 3 + 1).astype(np.uint32)
+        g.apply(2, xs, ys, v); o.apply(2, xs, ys, v)
+    assert g.stats()["clustered_mode"] == 1
+    for k in range(14):                                                # scrambled ids, other rows: the steady shape, short probes
+        xs = rng.integers(1000, 4000, 60000, dtype=np.uint32)
+        ys = (rng.integers(1, 150 + 6 * k, 60000, dtype=np.uint32) * 2654435761 % (1 << 31)).astype(np.uint32)
+        v = ((xs + ys) % 3 + 1).astype(np.uint32)
+        a, b = g.apply(2, xs, ys, v), o.apply(2, xs, ys, v)
+        kk = xs.astype(np.uint64) << 32 | ys
+        assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), k
+    assert g.stats()["clustered_mode"] == 0, g.stats()
+    assert (g.apply(0, x[:n], y[:n]) == o.apply(0, x[:n], y[:n])).all()
+    rows = o.list_rows()
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    g.close(); o.close(); gen.close()
