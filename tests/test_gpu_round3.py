@@ -587,9 +587,10 @@ def test_clustered_mode_comes_and_goes(G, oracle_mod):
         v = ((xs + ys) % 3 + 1).astype(np.uint32)
         g.apply(2, xs, ys, v); o.apply(2, xs, ys, v)
     assert g.stats()["clustered_mode"] == 1
-    for k in range(14):                                                # scrambled ids, other rows: the steady shape, short probes
+    for k in range(30):                                                # scrambled ids, other rows: the steady shape, short probes
+                                                                       # (9 of the first 14 batches are chained; 30 leave a wide margin)
         xs = rng.integers(1000, 4000, 60000, dtype=np.uint32)
-        ys = (rng.integers(1, 150 + 6 * k, 60000, dtype=np.uint32) * 2654435761 % (1 << 31)).astype(np.uint32)
+        ys = (rng.integers(1, 150 + 3 * k, 60000, dtype=np.uint32) * 2654435761 % (1 << 31)).astype(np.uint32)
         v = ((xs + ys) % 3 + 1).astype(np.uint32)
         a, b = g.apply(2, xs, ys, v), o.apply(2, xs, ys, v)
         kk = xs.astype(np.uint64) << 32 | ys
