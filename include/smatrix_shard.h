@@ -130,6 +130,9 @@ int smatrix_shard_apply_then_get_dev(smatrix_shard_t* sh, int op, size_t n, cons
  *   finish(h, out, out_get)   results back and into the caller's order (communication thread; returns when issued)
  *   wait(h, stream)           `stream` waits for the results; h is released (at most 4 batches may be in flight)
  * The communication thread works in call order, and every rank must make these calls in the same order.
+ * Threading: a shard handle is driven by ONE caller thread at a time -- "the same order on every rank" has no meaning
+ * otherwise.  The blocking calls serialise on the handle's lock; the split phases do not take it (a phase may block while
+ * another is issued for the next batch), only the pool of routed handles has a lock of its own.
  * The pipeline of the benchmark:  h1 = route(s+1);  apply_routed(h0);  finish(h0);  wait(h0);  h0 = h1. */
 typedef struct smatrix_routed smatrix_routed_t;
 smatrix_routed_t* smatrix_shard_route_dev(smatrix_shard_t* sh, int op, size_t n, const uint32_t* d_x, const uint32_t* d_y,

@@ -328,11 +328,21 @@ struct CellCache {
   static Ent* find(Shard& s, uint64_t h, uint64_t key, uint64_t* w) {
     Ent* tab = s.tab;
     if (!tab) return nullptr;
-    for (size_t i = (h >> 4) & (SLOTS - 1);; i = (i + 1) & (SLOTS - 1)) {
+    for (size_t i = (h >> 4) & (SLOTS - 1);;) {
       Ent& e = tab[i];
       const uint64_t word = e.word.load();
       if (w_state(word) == 0) return nullptr;
-      if (e.key.load(std::memory_order_relaxed) == key) { *w = word; return &e; }
+      if (e.key.load(std::memory_order_acquire) == key) {
+        // Validated like a seqlock: the word is read AGAIN behind the key.  A slot's key changes only after a
+        // wipe (word -> 0, then key, then a word of the NEXT generation), so a key read between two loads that show the
+        // same generation, both non-empty, belongs to those words.  Without the second load a reader that stalled between
+        // the two loads could pair the NEW key of a recycled slot with the OLD entry's value -- and a get would return
+        // another cell's value (writes were safe: their CAS fails on the generation).
+        const uint64_t again = e.word.load();
+        if (again == word || (w_state(again) != 0 && (again >> 34) == (word >> 34))) { *w = again; return &e; }
+        continue;                                        // recycled under us: look at this slot again
+      }
+      i = (i + 1) & (SLOTS - 1);
     }
   }
   // the host arithmetic of one op on a mirrored cell; false = not mirrored
@@ -1298,6 +1308,7 @@ void refresh_public(smatrix_t* self) {
 }
 
 void file_flush(smatrix_t* self, Matrix* m, bool all);
+void cache_sync(Matrix* m, bool drop);
 
 void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, const uint32_t* y,
                       const uint32_t* v, uint32_t* out, hipStream_t s) {
@@ -1310,8 +1321,12 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
   // thread writes dirty rows behind the caller's back all the time, src/smatrix.c:929-960; here it is a checkpoint)
   if (op != OP_GET && m->flush_every && self->fd && m->st.batches % m->flush_every == 0) {
     HIP_OK(hipStreamSynchronize(s));
-    m->dirty = false;
-    file_flush(self, m, false);
+    // (the protocol of smatrix_flush -- ADVICE r3: a plain `dirty = false` here lost the flag of a lock-free scalar write
+    //  that had landed on another mirrored cell a moment before, and smatrix_close then skipped its final flush)
+    if (m->dirty.exchange(false)) {
+      if (!m->in_cache_sync) cache_sync(m, false);
+      file_flush(self, m, false);
+    }
   }
 }
 
@@ -1332,9 +1347,20 @@ void cache_sync(Matrix* m, bool drop) {
   const uint32_t keep = m->in_stride;
   m->in_stride = 1;
   const uint64_t batches = m->st.batches;
+  // the write-back is not one of the caller's batches: the heuristics the next batch is planned from (speculative chain,
+  // bulk path, clustered mode) keep what the caller's last batch left (with the flusher calling this every
+  // 100 ms a young matrix got the chain and lost the bulk path on its next batch)
+  const bool k_ready = m->spec_ready, k_bulk = m->expect_bulk, k_long = m->long_probes, k_clu = m->clustered;
+  const uint32_t k_nd = m->spec_nd_prev, k_nt = m->spec_nt_prev, k_quiet = m->clustered_quiet;
+  const uint64_t k_gu = m->spec_gu_prev;
+  uint32_t k_nk[4];
+  memcpy(k_nk, m->spec_nk_prev, sizeof k_nk);
   m->in_cache_sync = true;
   run_write(m, OP_SET, (uint32_t)k, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);   // synchronises (set resolves duplicates last)
   m->in_cache_sync = false;
+  m->spec_ready = k_ready; m->expect_bulk = k_bulk; m->long_probes = k_long; m->clustered = k_clu;
+  m->spec_nd_prev = k_nd; m->spec_nt_prev = k_nt; m->clustered_quiet = k_quiet; m->spec_gu_prev = k_gu;
+  memcpy(m->spec_nk_prev, k_nk, sizeof k_nk);
   m->st.batches = batches;                                                     // bookkeeping of the caller's batches only
   m->in_stride = keep;
   m->cache.flushes++;
