@@ -825,6 +825,47 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
 
 
 
+def fail_rank(rank, why, code=3):
+    """one line, then out -- never re-exec, never hang (os._exit: no atexit handler may wait for a peer that is gone)"""
+    print("bench.py rank %d: %s" % (rank, why), file=sys.stderr, flush=True)
+    os._exit(code)
+
+
+class Watchdog:
+    """a timer thread that ends THIS process with a one-line reason when `seconds` pass before cancel()"""
+
+    def __init__(self, seconds, rank, what):
+        import threading
+        self._t = threading.Timer(seconds, fail_rank, args=(rank, "%s within %.0f s -- giving up" % (what, seconds), 4))
+        self._t.daemon = True
+        self._t.start()
+
+    def cancel(self):
+        self._t.cancel()
+
+
+def preflight_router(torch, dev, m, stream):
+    """the first collective calls of the C router on a matrix that stays empty: a get batch (reads of an empty matrix decide
+    nothing about the placement) through the blocking call and through the split phases -- count exchange, grouped
+    send/recv of records and results, gather"""
+    from libsmatrix_amd import OP_GET
+    n = 4096
+    x = torch.arange(1, n + 1, dtype=torch.int32, device=dev) * 7919
+    y = torch.arange(1, n + 1, dtype=torch.int32, device=dev)
+    out = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    m.apply_dev(OP_GET, x, y, None, out, stream)
+    torch.cuda.synchronize()
+    if int(out.abs().sum().item()) != 0:
+        raise RuntimeError("preflight: gets on an empty sharded matrix returned non-zero values")
+    h = m.route(OP_GET, x, y, None, False, stream)
+    m.apply_routed(h, False, stream)
+    m.finish(h, out)
+    m.wait(h, stream)
+    torch.cuda.synchronize()
+    if int(out.abs().sum().item()) != 0:
+        raise RuntimeError("preflight: split-phase gets on an empty sharded matrix returned non-zero values")
+
+
 def self_launch(n):
     """N ranks of this very command line as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
     environment, rendezvous on 127.0.0.1); rank 0 inherits stdout (its ONE JSON line), the others' stdout goes to
@@ -875,8 +916,13 @@ def main():
     ap.add_argument("--split-get", action="store_true",
                     help="sharded path: route the get batch on its own (two partitions and record exchanges per step, round 1's form)")
     ap.add_argument("--c-router", action="store_true",
-                    help="sharded path through the C library's own router (smatrix_shard_apply_then_get_dev: RCCL send/recv "
-                         "issued by the library, one partition + one record exchange per incr+get step)")
+                    help="(the default since round 4) sharded path through the C library's own router (include/smatrix_shard.h: RCCL "
+                         "send/recv issued by the library, one partition + one record exchange per incr+get step)")
+    ap.add_argument("--py-router", action="store_true",
+                    help="sharded path through the torch.distributed router (libsmatrix_amd/sharded.py) instead of the C library's")
+    ap.add_argument("--preflight-s", type=float, default=float(os.environ.get("SMATRIX_PREFLIGHT_S", "180")),
+                    help="N > 1: seconds the first contact with the other ranks may take (process group, RCCL communicator, one "
+                         "tiny routed batch) before this rank gives up with a one-line reason and a non-zero exit code")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
                     help="2 (default): the metric's workload; 3: getrow scan of the 13M-row CF matrix; 5: file round trip of it (one GPU)")
     ap.add_argument("--rows", type=int, default=None, help="--config 3/5: rows of the CF matrix (default 13M)")
@@ -924,14 +970,26 @@ def main():
         emit(line, json_out, "bench_detail_config%d.json" % args.config)
         return
     sharded = world > 1 or args.force_sharded
+    # N > 1 goes through the C library's router (north_star: "host C calling HIP ... RCCL alltoallv") unless --py-router
+    args.c_router = sharded and not args.py_router
+    watchdog = None
     if sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # single process, --force-sharded
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        # First contact with the other ranks (rendezvous, RCCL communicator creation, the first grouped send/recv) is where a
+        # multi-GPU run hangs if it hangs.  A rank that has not come through after --preflight-s seconds says why in ONE line
+        # and leaves with a non-zero code -- it never re-execs and never waits for ever; a parent started as `bench.py --gpus N`
+        # then ends the siblings (self_launch), torch.distributed.run does the same for its workers.
+        watchdog = Watchdog(args.preflight_s, rank, "first contact with the other ranks (process group / RCCL communicator / first "
+                                                     "routed batch) did not complete")
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.backend)
+        except Exception as e:                                  # noqa: BLE001
+            fail_rank(rank, "process group (%s) could not be created: %s: %s" % (args.backend, type(e).__name__, e))
 
     from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
     B = 1 << args.batch_lg
@@ -961,14 +1019,41 @@ def main():
         gen.fill_device(s * B, B, xs[s].data_ptr(), ys[s].data_ptr(), stream)
     torch.cuda.synchronize()
 
+    router_note = None
     if sharded and args.c_router:
         from libsmatrix_amd.sharded import NativeShardedMatrix
-        m = NativeShardedMatrix()
-    elif sharded:
+        m, why = None, None
+        try:
+            m = NativeShardedMatrix()
+            preflight_router(torch, dev, m, stream)
+        except Exception as e:                                  # noqa: BLE001
+            why = "%s: %s" % (type(e).__name__, e)
+        # every rank must take the same router: agree on the worst outcome
+        flag = torch.tensor([0 if why is None else 1], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            # the library's own RCCL path is not usable here (RCCL missing, communicator refused): say so once and take the
+            # torch.distributed router -- same partition kernels, same shards, the exchange issued by torch
+            print("bench.py rank %d: C router unavailable (%s) -- falling back to the torch.distributed router" % (rank, why or "a peer failed"),
+                  file=sys.stderr, flush=True)
+            if m is not None:
+                try:
+                    m.close()
+                except Exception:                                # noqa: BLE001
+                    pass
+            args.c_router = False
+            router_note = "fallback from the C router: %s" % (why or "a peer failed")
+    if sharded and not args.c_router:
         from libsmatrix_amd.sharded import ShardedMatrix
-        m = ShardedMatrix()
-    else:
+        try:
+            m = ShardedMatrix()
+        except Exception as e:                                  # noqa: BLE001
+            fail_rank(rank, "torch.distributed router could not be created: %s: %s" % (type(e).__name__, e))
+    elif not sharded:
         m = SparseMatrix()
+    if watchdog:
+        dist.barrier()
+        watchdog.cancel()
     # capacity hint (smatrix_reserve, like vector::reserve): the row arena of this workload ends at ~3.1 GB (6 GB after the
     # sustained leg); mapped up front, no growth step -- a call into the driver, which can block for seconds while it still
     # has a previous process's freed memory to wipe -- falls into the timed region.  The tables themselves still grow
@@ -1166,6 +1251,10 @@ def main():
                    "batch_ops": B, "arena_reserved_bytes": ARENA_RESERVE, "distinct_batches": ring, "parallelism": "row-hash shards x%d" % world if sharded else "single GPU"},
         "sanity_all_gets_positive": ok,
     }
+    if sharded:
+        res["config"]["router"] = ("c-library/%s" % m.transport) if args.c_router else "torch.distributed/%s" % args.backend
+        if router_note:
+            res["config"]["router_note"] = router_note
     if shard_info:
         res["config"]["placement"] = shard_info
     res.update(extras)

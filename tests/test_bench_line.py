@@ -53,3 +53,32 @@ def test_sharded_line_carries_router_and_placement():
                                                          "ops_applied_over_mean": [1.0] * 8}})
     line = json.loads(bench.short_line(full))
     assert line["config"]["router"] == "c" and line["config"]["placement"]["ops_applied_over_mean"] == [1.0] * 8
+
+
+def test_first_contact_watchdog_exits_with_one_line():
+    """N > 1: a rank whose first contact with the others (process group, RCCL communicator, first routed batch) does not
+    complete says why in ONE line and leaves with a non-zero code -- it never hangs and never re-execs"""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.Watchdog(0.3, 5, 'first contact did not complete'); time.sleep(30)" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+    assert p.returncode == 4
+    lines = [ln for ln in p.stderr.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("bench.py rank 5: first contact did not complete within"), p.stderr
+
+
+def test_self_launch_ends_the_siblings_of_a_failed_rank(tmp_path, monkeypatch):
+    """`bench.py --gpus N` as a launcher: when one rank exits non-zero the others are ended (by PID) and the launcher returns
+    that code instead of waiting for ranks that wait for a dead peer"""
+    import bench
+    import time
+    script = tmp_path / "fake_rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n"
+                      "    print('rank 1: giving up', file=sys.stderr); sys.exit(3)\n"
+                      "time.sleep(60)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    t0 = time.time()
+    assert bench.self_launch(3) == 3
+    assert time.time() - t0 < 20

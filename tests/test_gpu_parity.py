@@ -964,18 +964,19 @@ def test_sharded_two_ranks_one_gpu():
     assert p.returncode == 0 and "SHARDED_2RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world,router", [(2, "python"), (8, "python"), (8, "c")])
+@pytest.mark.parametrize("world,router", [(2, "c"), (8, "c"), (8, "python")])
 def test_bench_launch_contract_n_ranks(world, router):
     """`python bench.py --gpus N ...` AS GIVEN (no torch.distributed.run in front): bench.py spawns its own N ranks as
     child processes before it touches a GPU, rank 0 prints the ONE JSON line.  On the 1-GPU rig all ranks sit on cuda:0
     (gloo for the process group; the payload staged through the host / the C router's shared-memory transport).  N > 1 is
     config 4 (8M x 8M ids, one stream per rank).  At 8 ranks -- the node size of the scaling run -- the planned placement
     must leave every shard within 10 % of the mean load; equal hash ranges put 1.9x the mean on the owner of the hottest
-    row.  router = "c": the same through the C library's own router (include/smatrix_shard.h)."""
+    row.  router = "c" (the default since round 4): the C library's own router (include/smatrix_shard.h), after a preflight
+    batch under a watchdog; "python": --py-router, the torch.distributed one."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--batch-lg", "18" if world == 2 else "20", "--backend", "gloo", "--single-device"] + (["--c-router"] if router == "c" else [])
+           "--batch-lg", "18" if world == 2 else "20", "--backend", "gloo", "--single-device"] + (["--py-router"] if router == "python" else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
@@ -985,6 +986,9 @@ def test_bench_launch_contract_n_ranks(world, router):
     assert res["n_gpus"] == world and res["steps"] == 3 and res["scaling"] == "weak" and res["sanity_all_gets_positive"]
     assert res["value"] > 0 and "roofline" in res
     assert res["config"]["workload"].startswith("config-4") and res["config"]["ids_per_axis"] == 8000000
+    # the C library's router is the default N > 1 path (round 4); --py-router selects the torch.distributed one
+    assert res["config"]["router"] == ("c-library/shm" if router == "c" else "torch.distributed/gloo"), res["config"]
+    assert len(lines[0]) < 4096
     pl = res["config"]["placement"]
     assert pl["rows_placed_by_load"] > 0 and len(pl["ops_applied_over_mean"]) == world
     if world == 8:
