@@ -96,6 +96,8 @@ def short_line(full, detail_path=None):
         line["steady_state_all_hits"] = _pick(full["steady_state_all_hits"], "steps", "ms_per_step", "Mops_per_s")
     if isinstance(full.get("cold_start"), dict):
         line["cold_start"] = _pick(full["cold_start"], "first_step_ms", "over_timed_step")
+    if isinstance(full.get("table"), dict):
+        line["table"] = _pick(full["table"], "rows", "batches", "rounds", "rows_grown", "spec_chains", "spec_refused")
     if "sanity_all_gets_positive" in full:
         line["sanity_all_gets_positive"] = full["sanity_all_gets_positive"]
     summ = {"sustained_ms_per_step_median_group": g(full, "sustained", "ms_per_step_median_group"),
@@ -119,7 +121,7 @@ def short_line(full, detail_path=None):
     line = _r(line)
     text = json.dumps(line, separators=(",", ":"))
     # never let an unexpected field push the line out of the driver's window: shed the optional parts, largest first
-    for k in ("legs", "steady_state_all_hits", "cold_start", "roofline_get", "random_access"):
+    for k in ("legs", "table", "steady_state_all_hits", "cold_start", "roofline_get", "random_access"):
         if len(text) < LINE_MAX:
             break
         line.pop(k, None)
