@@ -333,7 +333,8 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
                                      bool* deferred, LongProbe* lp, bool dbg_noticket = false, bool no_ret = false,
-                                     bool exists_only = false) {
+                                     bool exists_only = false, uint64_t* where_out = nullptr) {
+  // where_out (writers, y != 0): the cell the op ended at, as an index into the arena's 8-byte cells (k_set_fold)
   uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
@@ -385,7 +386,10 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         const uint32_t first = OP == OP_DECR ? 0u - V : V;
         uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull,
                                   (unsigned long long)pack_cell(Y, first));
-        if (prev == 0) return first;
+        if (prev == 0) {
+          if (where_out) *where_out = ((uint64_t)s.z << 4) + pos;
+          return first;
+        }
         if (!dbg_noticket) atomicSub(ticket, 1u);        // lost the slot: give the ticket back
         c = prev;
         continue;                                        // re-examine what is there now
@@ -396,6 +400,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
       c = cells[pos];
     }
     uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
+    if (where_out) *where_out = ((uint64_t)s.z << 4) + pos;
     if (OP == OP_INCR) result = atomicAdd(vp, V) + V;      // :241, wraps mod 2^32
     else if (OP == OP_DECR) result = atomicSub(vp, V) - V; // :252
     else { result = V; if (!exists_only) atomicExch(vp, V); }   // :230 (duplicates: see k_set_locate; exists_only: k_set_fold's
@@ -445,7 +450,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
                                      uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false,
-                                     bool no_ret = false, bool exists_only = false) {
+                                     bool no_ret = false, bool exists_only = false, uint64_t* where_out = nullptr) {
   uint4 s;
   DirSlot* d = dir_find(dir, dmask, X, &s);
   if (!d || s.z == 0) {
@@ -453,7 +458,7 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
     return 0;
   }
   return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket, no_ret,
-                                      exists_only);
+                                      exists_only, where_out);
 }
 
 #ifndef SMX_APPLY_SGPRS
@@ -927,7 +932,13 @@ template <uint32_t ST = 1>
 __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_set_fold(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, const uint32_t* __restrict__ vs,
-    uint32_t* __restrict__ out, uint32_t* defer, uint32_t* __restrict__ ent_idx) {
+    uint32_t* __restrict__ out, uint32_t* defer, uint32_t* __restrict__ ent_idx, uint64_t* __restrict__ ent_cell) {
+  // ent_cell[e]: the cell the entry's key lives in, as found (or created) HERE, its value word cleared for the ranking pass.
+  // The address holds while no row is created or doubled: a batch that round 0 completes -- every key present, or
+  // inserted without a structure change -- goes straight to the ranking pass and spares k_set_locate_e, the most
+  // expensive of the entry passes (0.93 of 2.67 ms per 2^24 sets on present keys).  Clearing early is harmless: every
+  // cell a set op names ends the batch with its winner's value, a (key, 0) cell stays a live cell for every probe and
+  // rehash, and all clears of this kernel are over before the first atomicMax of the next one.
   __shared__ uint64_t l_key[AGG_SLOTS];     // (x | y<<32), 0 = empty
   __shared__ uint32_t l_win[AGG_SLOTS];     // highest op index + 1 among the tile's ops on the key
   __shared__ uint16_t l_list[AGG_TILE];
@@ -969,11 +980,14 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       const uint32_t w = l_win[h] - 1u;
       bool deferred = false;
       LongProbe lp{false, nullptr, 0, 0};
+      uint64_t where = ~0ull;
       apply_one<OP_SET, true, 1>(dir, dmask, arena, (uint32_t)key, (uint32_t)(key >> 32), vs[(size_t)w * ST], &deferred, &lp,
-                                 false, false, true);
+                                 false, false, true, &where);
       if (lp.need) { deferred = true; ctl->n_long = 1; }
-      if (deferred) { dm |= 1u << q; wj[q] = w; }
+      if (deferred) { dm |= 1u << q; wj[q] = w; where = ~0ull; }
       e = w + 1u;
+      if (where != ~0ull) reinterpret_cast<uint32_t*>(arena)[where * 2 + 1] = 0;
+      ent_cell[tile0 + i] = where;
     }
     ent_idx[tile0 + i] = e;                 // (the entry arrays hold gridDim.x * AGG_TILE slots)
   }

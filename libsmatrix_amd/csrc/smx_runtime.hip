@@ -493,6 +493,7 @@ struct Matrix {
   DevBuf<uint64_t> soff;
   bool no_ret = false;                  // the write batch in flight has no result array (d_out == NULL, CF import)
   uint32_t set_entries = 0;             // set batch in flight: entries of k_set_fold (0: the batch went op by op)
+  bool set_always_locate = false;       // SMATRIX_SET_LOCATE=1 (tests, A/B): the entry passes always start with k_set_locate_e
   DevBuf<uint32_t> ent_idx;
   DevBuf<uint32_t> big;                 // getrow: rows too large for one wave
   DevBuf<uint32_t> seg;                 // getrow: their segments (first segment per row, then a count per segment)
@@ -707,9 +708,9 @@ void launch_apply_op(Matrix* m, int op, hipStream_t s, uint32_t n, const uint32_
         m->set_entries = tiles * AGG_TILE;
         m->ent_idx.need(m->set_entries);
         if (m->in_stride == 3)
-          hipLaunchKernelGGL((k_set_fold<3>), dim3(tiles), dim3(AGG_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, v, out, defer, m->ent_idx.p);
+          hipLaunchKernelGGL((k_set_fold<3>), dim3(tiles), dim3(AGG_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, v, out, defer, m->ent_idx.p, m->cellp.p);
         else
-          hipLaunchKernelGGL((k_set_fold<1>), dim3(tiles), dim3(AGG_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, v, out, defer, m->ent_idx.p);
+          hipLaunchKernelGGL((k_set_fold<1>), dim3(tiles), dim3(AGG_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, v, out, defer, m->ent_idx.p, m->cellp.p);
         HIP_OK(hipGetLastError());
       } else {
         launch_apply<OP_SET>(m, s, n, idx, x, y, v, out, defer);
@@ -1045,6 +1046,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   m->long_probes = false;
   uint32_t rounds_this_batch = 0;
   bool cold_tried = false;
+  bool structure_stable = false;        // round 0 completed the batch: no row was created or doubled (set: the fold's cell addresses hold)
   // the chain is tried when the previous write batch was finished by its round 1 (or by the chain itself)
   bool chain = m->spec_enabled && m->spec_ready && !m->expect_bulk && n >= m->agg_min && m->dbg_after == 0;
   for (uint32_t round = 0;; round++) {
@@ -1204,7 +1206,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         m->clustered_quiet = (uint64_t)c.n_long_ops * 256 < n ? m->clustered_quiet + 1 : 0;
         if (m->clustered_quiet >= 8) m->clustered = false;
       }
-      if (nd_chain0 == 0) break;                               // round 0 deferred nothing: the rest of the chain ran empty
+      if (nd_chain0 == 0) { structure_stable = true; break; }  // round 0 deferred nothing: the rest of the chain ran empty
       cur_n = nd_chain0;
       round = pre_pass ? 2 : 1;                                // (the next round writes the list that `dl` is NOT)
     } else if (m->trace_rounds) {
@@ -1225,7 +1227,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       // the steady shape: remember what round 0 needed -- the next batch's chain is sized from it
       m->spec_nd_prev = cur_n;
     }
-    if (nd == 0) break;
+    if (nd == 0) { structure_stable = round == 0 && !chained; break; }
     if (m->h_ctl->n_long) { m->long_probes = true; m->st.long_probe_rounds++; }
     // clustered: percents of a batch needed the wave-cooperative probe (dense ids: 4-5 %; any large table at load 1/2 has a few
     // sequences beyond the budget -- the first batches of the scrambled stream do -- and must not switch it on)
@@ -1260,7 +1262,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // highest-index-wins across tiles, over the winners of k_set_fold only (locate also clears the value word)
     const uint32_t ne = m->set_entries;
     dim3 g(blocks_for(ne)), b(256);
-    hipLaunchKernelGGL(k_set_locate_e, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, ne, x, y, m->ent_idx.p, m->cellp.p, m->in_stride);
+    // (round 0 completed the batch: every entry's cell is where k_set_fold found or created it, already cleared)
+    if (!structure_stable || m->set_always_locate)
+      hipLaunchKernelGGL(k_set_locate_e, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, ne, x, y, m->ent_idx.p, m->cellp.p, m->in_stride);
+    else m->st.set_located_by_fold++;
     hipLaunchKernelGGL(k_set_rank_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_pick_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_store_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, v, m->arena.base, m->in_stride);
@@ -1463,6 +1468,7 @@ smatrix_t* smatrix_open(const char* fname) {
   dev_malloc(&m->d_small, 64);
   HIP_OK(hipHostMalloc(&m->h_small, 64));
   HIP_OK(hipHostMalloc(&m->h_row, 32 + (size_t)SCALAR_ROW_PAIRS_ALLOC * 8));
+  if (const char* a = getenv("SMATRIX_SET_LOCATE")) m->set_always_locate = *a == '1';
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE_CAP")) m->cache.shard_cap = std::max<size_t>(4, std::min<size_t>(strtoull(a, nullptr, 10), CellCache::SLOTS / 2));   // (tests: constant recycling)
   HIP_OK(hipEventCreate(&m->ev0));

@@ -78,3 +78,43 @@ def test_scalar_mirror_get_never_returns_another_cells_value(G, monkeypatch):
     assert not bad, bad[:5]
     assert (g.m.get_batch(np.full(cy.size, x0, np.uint32), cy) == 1000 + np.arange(cy.size)).all()
     g.close()
+
+
+@pytest.mark.parametrize("mode", ["fold", "locate"])
+def test_set_batch_on_present_keys_uses_the_folds_cells(G, oracle_mod, monkeypatch, mode):
+    """Round 4: a set batch that round 0 completes (no row created or doubled) ranks its entries at the cells k_set_fold
+    found -- cleared there -- and spares the locate pass; highest-index-wins across tiles (src/smatrix.c:225-234 under the
+    batch contract) must hold exactly as with the pass (SMATRIX_SET_LOCATE=1).  Zipf keys: hot cells are written from
+    hundreds of tiles.  Then a batch that DOES insert and grow rows (the pass runs), then present keys again -- the
+    table's addresses have changed in between."""
+    if mode == "locate":
+        monkeypatch.setenv("SMATRIX_SET_LOCATE", "1")
+    rng = np.random.default_rng(99)
+    n = 1 << 20
+    g, o = G(), oracle_mod.Oracle()
+    # (scrambled column ids: an odd multiplier is a bijection of the 32-bit ids.  Dense ids cluster under the reference's
+    #  identity hash, the fold then hands its long probes to the lane-per-op retry and the batch is not "completed by round 0")
+    scr = lambda a: (a.astype(np.uint64) * np.uint64(2654435761) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    x = (rng.zipf(1.3, n) % 3000).astype(np.uint32); y = scr((rng.zipf(1.2, n) % (1 << 20)).astype(np.uint32) + 1)
+    ones = np.ones(n, np.uint32)
+    g.apply(2, x, y, ones); o.apply(2, x, y, ones)                       # build
+    before = g.stats()["set_located_by_fold"]
+    for rep in range(3):
+        p = rng.permutation(n)
+        v = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+        a = g.apply(1, x[p], y[p], v); o.apply(1, x[p], y[p], v)
+        assert (a == v).all()
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rep
+    assert g.stats()["set_located_by_fold"] - before == (3 if mode == "fold" else 0)
+    # new keys + growth in a set batch, y == 0 ops in it as well (quirk path, applied in place)
+    x2 = (rng.zipf(1.3, n) % 4000).astype(np.uint32); y2 = scr((rng.zipf(1.2, n) % (1 << 21)).astype(np.uint32))
+    v2 = rng.integers(1, 1 << 32, n, dtype=np.uint32)
+    g.apply(1, x2, y2, v2); o.apply(1, x2, y2, v2)
+    nz = y2 != 0
+    assert (g.apply(0, x2[nz], y2[nz]) == o.apply(0, x2[nz], y2[nz])).all()
+    rows = np.unique(np.concatenate([x, x2]))
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], np.uint32)).all()
+    v3 = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+    g.apply(1, x, y, v3); o.apply(1, x, y, v3)
+    assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
+    g.close(); o.close()
