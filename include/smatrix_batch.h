@@ -159,14 +159,19 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
  * reference's own scheme, src/smatrix.c:418-496); row blocks first, then the entries that publish them.  smatrix_close
  * does the same one last time.  The reference has no such call: its IO thread flushes continuously (:929-960) and
  * close is its only barrier (:113-133).  Like the reference's IO thread (100 ms poll, :945) a background flusher of this
- * library writes dirty rows every SMATRIX_FLUSH_MS milliseconds (default 100, 0 = off; it holds the matrix lock while it
- * writes and therefore pauses for ten times as long as its last flush took), so a process that dies without close
- * loses about that much.  SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch, SMATRIX_FSYNC=1
- * adds fsync() after the row blocks and after the entries.  Memory mode: no-op.  Returns 0. */
+ * library writes dirty rows every SMATRIX_FLUSH_MS milliseconds (default 100, 0 = off), so a process that dies without
+ * close loses about that much.  Both -- this call and the background flusher -- hold the matrix lock only while the dirty
+ * rows are collected, laid out and SNAPSHOT on the device (at most SMATRIX_FLUSH_SNAPSHOT_MB = 2048 MB of row tables at a
+ * time; a larger backlog goes out in several such steps); the copies to the host and the writes run without it, as the
+ * reference's IO thread writes under per-row read locks only (:929-960): callers on other threads keep their latency
+ * (measured: a 1 GB flush, batch gets p99 23 -> 25 us).  A row that changes while a flush writes goes out with the next.
+ * SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch (inside that call), SMATRIX_FSYNC=1 adds fsync() after the
+ * row blocks and after the entries.  Memory mode: no-op.  Returns 0. */
 int smatrix_flush(smatrix_t* self);
-/* File mode: rewrites the backing file without the blocks that grown rows have left behind (like the reference's, the
- * file otherwise only grows, src/smatrix.c:430-436): all rows into a new file next to it, fsync, rename over the old
- * one.  Needs room for a second copy while it runs.  SMATRIX_COMPACT_AT_CLOSE=1 does it at close.  Returns 0. */
+/* EXPERIMENTAL, no reference counterpart (the reference's files only grow: resized rows leave their old block behind,
+ * src/smatrix.c:430-436, and so do this library's -- same format, same leak): rewrites the backing file without those
+ * blocks, all rows into a new file next to it, fsync, rename over the old one.  Needs room for a second copy while it
+ * runs.  SMATRIX_COMPACT_AT_CLOSE=1 does it at close.  Not part of the drop-in surface; may change.  Returns 0. */
 int smatrix_compact(smatrix_t* self);
 /* on: time every round-0 op kernel with HIP events on its stream (adds one sync per
  * batch); resets the kernel_* accumulators.  Also enabled by SMATRIX_PROFILE=1. */

@@ -3047,11 +3047,16 @@ __global__ __launch_bounds__(256) void k_cf_expand(uint64_t t0, uint32_t count, 
 // ---- persistence: dirty rows (src/smatrix.c:418-425 rmap_sync_defer, :929-960 the IO thread's queue) --------
 // k_dirty_collect: every directory slot marked META_DIRTY is copied to `out` and unmarked (one list reservation per
 // workgroup).  With all != 0 every row is taken (first write of a file, compaction).
+// budget (bytes of row cells; ~0: none): the flush that snapshots its rows on the device takes only so much at a time.
+// A workgroup reserves its rows' bytes with one add on count[1..2]; a share that STARTS beyond the budget is left as
+// it is -- rows stay marked, count[3] says that more is waiting -- so one call takes the budget plus at most one
+// workgroup's rows.
 __global__ __launch_bounds__(256) void k_dirty_collect(DirSlot* dir, uint32_t dir_size, uint32_t all, DirSlot* out,
-                                                       uint32_t cap, uint32_t* count) {
-  __shared__ uint32_t l_n, l_base;
+                                                       uint32_t cap, uint32_t* count, unsigned long long budget) {
+  __shared__ uint32_t l_n, l_base, l_ok;
+  __shared__ unsigned long long l_bytes;
   for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < dir_size; i0 += gridDim.x * blockDim.x) {     // block-uniform
-    if (threadIdx.x == 0) l_n = 0;
+    if (threadIdx.x == 0) { l_n = 0; l_bytes = 0; l_ok = 1; }
     __syncthreads();
     const uint32_t i = i0 + threadIdx.x;
     DirSlot d = {0, 0, 0, 0};
@@ -3061,11 +3066,20 @@ __global__ __launch_bounds__(256) void k_dirty_collect(DirSlot* dir, uint32_t di
       take = (d.meta & META_USED) && d.base != 0 && (all || (d.meta & META_DIRTY));
     }
     uint32_t rank = 0;
-    if (take) rank = atomicAdd(&l_n, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0 && l_n) l_base = atomicAdd(count, l_n);
-    __syncthreads();
     if (take) {
+      rank = atomicAdd(&l_n, 1u);
+      if (budget != ~0ull) atomicAdd(&l_bytes, 16ull + (8ull << meta_lg(d.meta)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && l_n) {
+      if (budget != ~0ull) {
+        const unsigned long long before = atomicAdd(reinterpret_cast<unsigned long long*>(count + 2), l_bytes);   // (count + 2 is 8-byte aligned)
+        if (before >= budget) { l_ok = 0; count[1] = 1; }
+      }
+      if (l_ok) l_base = atomicAdd(count, l_n);
+    }
+    __syncthreads();
+    if (take && l_ok) {
       if (d.meta & META_DIRTY) dir[i].meta = d.meta & ~META_DIRTY;
       const uint32_t at = l_base + rank;
       if (at < cap) { d.meta &= ~META_DIRTY; out[at] = d; }

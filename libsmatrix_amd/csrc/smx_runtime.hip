@@ -526,6 +526,12 @@ struct Matrix {
   // back, 100 ms poll :945): a timer thread that runs cache_sync + file_flush under the matrix lock every
   // SMATRIX_FLUSH_MS (default 100; 0 = off), never more than ~1/10 of the time (the pause grows with the last flush)
   uint64_t flush_ms = 100;
+  // flushes that release the matrix lock while they write (file_flush, snapshot mode): the FILE and its index belong to the
+  // holder of file_mu; lock order m->mu, then file_mu -- and nobody waits for m->mu while holding file_mu
+  std::mutex file_mu;
+  uint64_t flush_snapshot = 2048ull << 20;   // bytes of row tables one such flush snapshots on the device (SMATRIX_FLUSH_SNAPSHOT_MB)
+  hipStream_t flush_stream = nullptr;        // its copies to the host
+  std::atomic<uint64_t> file_flushes_done{0}, file_rows_written_done{0}, file_bg_flushes_done{0};
   std::thread flusher;
   std::mutex fl_mu;
   std::condition_variable fl_cv;
@@ -1312,7 +1318,7 @@ void refresh_public(smatrix_t* self) {
   self->mem = (uint64_t)m->dir_size * sizeof(DirSlot) + live_units * UNIT_BYTES;
 }
 
-void file_flush(smatrix_t* self, Matrix* m, bool all);
+bool file_flush(smatrix_t* self, Matrix* m, bool all, std::unique_lock<std::mutex>* unlock);
 void cache_sync(Matrix* m, bool drop);
 
 void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, const uint32_t* y,
@@ -1330,7 +1336,8 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
     //  that had landed on another mirrored cell a moment before, and smatrix_close then skipped its final flush)
     if (m->dirty.exchange(false)) {
       if (!m->in_cache_sync) cache_sync(m, false);
-      file_flush(self, m, false);
+      std::lock_guard<std::mutex> fg(m->file_mu);
+      file_flush(self, m, false, nullptr);
     }
   }
 }
@@ -1390,19 +1397,24 @@ void flusher_main(smatrix_t* self, Matrix* m) {
     auto pause = period;
     if (m->dirty.load()) {
       const auto t0 = clock::now();
+      bool more = false;
       {
         set_device(m);
-        std::lock_guard<std::mutex> g(m->mu);
+        std::unique_lock<std::mutex> g(m->mu);
         if (m->dirty.exchange(false)) {
           cache_sync(m, false);
-          file_flush(self, m, false);
-          m->st.file_bg_flushes++;
+          std::lock_guard<std::mutex> fg(m->file_mu);
+          // (round 4) the lock is held while the dirty rows are collected, laid out and snapshot on the device, and goes
+          // back to the callers BEFORE the bytes are copied to the host and written (file_flush releases `g`)
+          more = file_flush(self, m, false, &g);
+          m->file_bg_flushes_done.fetch_add(1);
+          if (more) m->dirty = true;                 // the snapshot budget was reached: the rest goes out with the next one
         }
       }
-      // a flush holds the matrix lock: keep it to about a tenth of the time (a 4 s flush of a 27 GB matrix is
-      // followed by 40 s without one; small matrices stay at the period)
+      // the device copies and the writes of a flush compete with the callers for PCIe and the page cache: keep them to
+      // about a tenth of the time (small matrices stay at the period); a flush that left rows behind goes on at once
       const auto took = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0);
-      pause = std::max(period, took * 10);
+      pause = more ? std::chrono::milliseconds(1) : std::max(period, took * 10);
     }
     l.lock();
     next = clock::now() + pause;
@@ -1418,10 +1430,17 @@ int smatrix_flush(smatrix_t* self) {
   Matrix* m = M(self);
   if (m->fname.empty() || !self->fd) return 0;
   set_device(m);
-  std::lock_guard<std::mutex> g(m->mu);
-  if (m->dirty.exchange(false)) {
-    cache_sync(m, false);
-    file_flush(self, m, false);
+  // (like the background flusher: callers of other threads are held up only while the rows are snapshot on the device, not
+  //  while they are written; the call itself returns when everything that was dirty at its start is in the file)
+  for (bool more = true; more;) {
+    std::unique_lock<std::mutex> g(m->mu);
+    more = false;
+    if (m->dirty.exchange(false)) {
+      cache_sync(m, false);
+      std::lock_guard<std::mutex> fg(m->file_mu);
+      more = file_flush(self, m, false, &g);
+      if (more) m->dirty = true;
+    }
   }
   return 0;
 }
@@ -1433,6 +1452,7 @@ int smatrix_compact(smatrix_t* self) {
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, false);
+  std::lock_guard<std::mutex> fg(m->file_mu);
   file_compact(self, m);
   return 0;
 }
@@ -1469,6 +1489,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipHostMalloc(&m->h_small, 64));
   HIP_OK(hipHostMalloc(&m->h_row, 32 + (size_t)SCALAR_ROW_PAIRS_ALLOC * 8));
   if (const char* a = getenv("SMATRIX_SET_LOCATE")) m->set_always_locate = *a == '1';
+  if (const char* a = getenv("SMATRIX_FLUSH_SNAPSHOT_MB")) m->flush_snapshot = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE_CAP")) m->cache.shard_cap = std::max<size_t>(4, std::min<size_t>(strtoull(a, nullptr, 10), CellCache::SLOTS / 2));   // (tests: constant recycling)
   HIP_OK(hipEventCreate(&m->ev0));
@@ -1542,8 +1563,9 @@ void smatrix_close(smatrix_t* self) {
     {
       std::lock_guard<std::mutex> g(m->mu);
       cache_sync(m, true);
+      std::lock_guard<std::mutex> fg(m->file_mu);
       if (!m->fname.empty() && self->fd && m->compact_at_close) file_compact(self, m);
-      else if (!m->fname.empty() && self->fd && m->dirty.exchange(false)) file_flush(self, m);   // a matrix that was only read has nothing to persist
+      else if (!m->fname.empty() && self->fd && m->dirty.exchange(false)) file_flush(self, m, false, nullptr);   // a matrix that was only read has nothing to persist
       (void)hipStreamSynchronize(m->stream);
       PhaseClock clk(m->trace_rounds, "close");
       m->arena.destroy();
@@ -1568,6 +1590,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
       if (m->ev_join) (void)hipEventDestroy(m->ev_join);
       if (m->helper) (void)hipStreamDestroy(m->helper);
+      if (m->flush_stream) (void)hipStreamDestroy(m->flush_stream);
       if (m->stream) (void)hipStreamDestroy(m->stream);
       clk.lap("buffers freed");
     }
@@ -2131,6 +2154,9 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   m->st.scalar_cache_flushes = m->cache.flushes.load();
   m->st.scalar_cache_flushed_cells = m->cache.flushed_cells.load();
   m->st.file_leaked_bytes = m->file_index ? file_leaked(m) : 0;
+  m->st.file_flushes = m->file_flushes_done.load();
+  m->st.file_rows_written = m->file_rows_written_done.load();
+  m->st.file_bg_flushes = m->file_bg_flushes_done.load();
   m->st.clustered_mode = m->clustered ? 1 : 0;
   *out = m->st;
 }
