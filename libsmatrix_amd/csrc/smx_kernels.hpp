@@ -1424,6 +1424,68 @@ __global__ __launch_bounds__(256) void k_fix_create(Ctl* ctl, DirSlot* dir, uint
   }
 }
 
+// pass 0a (round 4): HOW MANY rows will pass 0 create?  The first batch of a matrix names 10^5..10^6 rows the directory
+// (65 536 slots at open, src/smatrix.c:601) does not hold; pass 0 used to run into "directory full", the host rebuilt the
+// directory four times as large and ran the pass again -- four passes over 15 M ops and three rebuilds for the first batch
+// of config 2 (1.6 ms of its 13 ms).  Here the distinct MISSING row ids of the list are counted exactly -- the tile's ids
+// folded in LDS like pass 0, each distinct id looked up once, the missing ones entered into a scratch set (64-bit slots,
+// id + 1; a plain look before the compare-and-swap: hot ids are named by every tile) -- and the host sizes the directory
+// ONCE.  The directory's layout is not observable through the API (the cmap rows), so sizing it in one step
+// instead of four changes nothing a caller can see.
+__global__ __launch_bounds__(256) void k_fix_count_rows(const DirSlot* dir, uint32_t dmask, uint32_t n, const uint32_t* defer,
+                                                        const uint32_t* __restrict__ xs, uint32_t st, unsigned long long* set,
+                                                        uint64_t set_mask, uint32_t* n_missing) {
+  __shared__ uint32_t l_key[FIXR_SLOTS];
+  __shared__ uint32_t l_won, l_none;
+  for (uint32_t t0 = blockIdx.x * 256u * FIXR_OPT; t0 < n; t0 += gridDim.x * 256u * FIXR_OPT) {   // block-uniform
+    for (uint32_t i = threadIdx.x; i < FIXR_SLOTS; i += 256) l_key[i] = FIX_NONE;
+    if (threadIdx.x == 0) { l_won = 0; l_none = 0; }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t k = 0; k < FIXR_OPT; k++) {
+      const uint32_t t = t0 + k * 256u + threadIdx.x;
+      if (t >= n) continue;
+      const uint32_t X = xs[(size_t)defer[t] * st];
+      if (X == FIX_NONE) { l_none = 1; continue; }                  // (the id that cannot use the LDS set: counted as one more row)
+      uint32_t q = (X * 0x9E3779B1u) >> 19;                         // 13 bits
+      for (;;) {
+        const uint32_t prev = atomicCAS(&l_key[q], FIX_NONE, X);
+        if (prev == FIX_NONE || prev == X) break;
+        q = (q + 1) & (FIXR_SLOTS - 1);
+      }
+    }
+    __syncthreads();
+    uint32_t won = 0;
+    for (uint32_t i = threadIdx.x; i < FIXR_SLOTS; i += 256) {
+      const uint32_t X = l_key[i];
+      if (X == FIX_NONE) continue;
+      uint32_t h = fmix32(X) & dmask;
+      bool missing = false;
+      for (;;) {
+        const uint64_t cur = *reinterpret_cast<const uint64_t*>(&dir[h]);          // (the directory is stable during this pass)
+        if (cur == 0) { missing = true; break; }
+        if ((uint32_t)(cur >> 32) == X) break;
+        h = (h + 1) & dmask;
+      }
+      if (!missing) continue;
+      const unsigned long long key = (unsigned long long)X + 1ull;
+      uint64_t g = splitmix_at(0x0d1full, X) & set_mask;
+      for (;;) {
+        unsigned long long prev = set[g];
+        if (prev == 0ull) prev = atomicCAS(&set[g], 0ull, key);
+        if (prev == 0ull) { won++; break; }
+        if (prev == key) break;
+        g = (g + 1) & set_mask;
+      }
+    }
+    if (won) atomicAdd(&l_won, won);
+    __syncthreads();
+    if (threadIdx.x == 0 && l_won) atomicAdd(n_missing, l_won);
+    if (threadIdx.x == 0 && l_none) n_missing[1] = 1;               // (benign race: all store 1)
+    __syncthreads();
+  }
+}
+
 // pass 1: ops per directory slot; where[t] = the slot of deferred op t, or FIX_NONE for an op the bulk path does not take.
 // A workgroup first folds its 2048 ops by slot in an LDS table (bulk loads name the same row many times in a row:
 // the config-3 stream has 115 consecutive ops per row), then adds each distinct slot's count with ONE global atomic.
@@ -1490,6 +1552,15 @@ constexpr uint32_t SCAN_TILE = 2048;
 __device__ inline bool fix_row_eligible(const DirSlot& d, uint32_t c) {
   return fix_bound_lg(d.used, c, meta_lg(d.meta)) <= FIX_MAX_LG && !(d.meta & (META_GROW | META_REBAL));
 }
+// Round 4: a row that is still SMALL but could outgrow the path (the hot rows of a first batch: millions of ops on a
+// 16-cell table) gives the path its first FIX_PART_OPS ops: the wide pass takes the row as far as 2^FIX_MAX_LG cells filled to
+// the reference's threshold and hands the rest back.  Any subset of a batch's ops may come first in its serialisation, so
+// this is the state a cold start reaches after its first five doubling rounds (16 -> 512 cells) -- without those rounds
+// (the first batch of config 2: 3 578 such rows, 5 of its 16 rounds).
+constexpr uint32_t FIX_PART_OPS = 2048;
+__device__ inline bool fix_row_partial(const DirSlot& d, uint32_t c) {
+  return meta_lg(d.meta) <= FIX_MAX_LG && !(d.meta & (META_GROW | META_REBAL)) && fix_bound_lg(d.used, c, meta_lg(d.meta)) > FIX_MAX_LG;
+}
 __device__ inline uint64_t fix_elem(const DirSlot* dir, const uint32_t* cnt, const uint32_t* touched, uint32_t i, uint32_t nrows,
                                     uint64_t* wide) {
   if (i >= nrows) return 0;
@@ -1497,6 +1568,10 @@ __device__ inline uint64_t fix_elem(const DirSlot* dir, const uint32_t* cnt, con
   const uint32_t c = cnt[h];
   const DirSlot d = dir[h];
   const uint32_t lg = meta_lg(d.meta), lgb = fix_bound_lg(d.used, c, lg);
+  if (fix_row_partial(d, c)) {                                     // its first ops, and a block of the largest class
+    *wide = 1;
+    return (uint64_t)min(c, FIX_PART_OPS) | ((uint64_t)(lg < FIX_MAX_LG ? (uint32_t)units_of_lg(FIX_MAX_LG) : 0u) << 32);
+  }
   if (!fix_row_eligible(d, c)) return 0;                           // its ops go straight back to the list (k_fix_scatter)
   if (lgb == FIX_MAX_LG) *wide = 1;                                // the second k_fix_rows pass has work (benign race: all store 1)
   return (uint64_t)c | ((uint64_t)(lgb > lg ? (uint32_t)units_of_lg(lgb) : 0u) << 32);
@@ -1569,6 +1644,7 @@ __global__ __launch_bounds__(256) void k_fix_scatter(Ctl* ctl, const DirSlot* di
   // row, took 27 ms for the 4 M ops of one hot item)
   constexpr uint32_t BACK = 0x80000000u;
   __shared__ uint32_t l_key[FIXC_SLOTS], l_cnt[FIXC_SLOTS];
+  __shared__ uint32_t l_take[FIXC_SLOTS], l_over[FIXC_SLOTS];      // partial rows: ops of this workgroup the path takes; where its other ops go back
   __shared__ uint32_t l_nback, l_bbase;
   for (uint32_t t0 = blockIdx.x * 256u * FIXC_OPT; t0 < n; t0 += gridDim.x * 256u * FIXC_OPT) {   // block-uniform
     for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) { l_key[i] = FIX_NONE; l_cnt[i] = 0; }
@@ -1590,20 +1666,31 @@ __global__ __launch_bounds__(256) void k_fix_scatter(Ctl* ctl, const DirSlot* di
       rk[k] = atomicAdd(&l_cnt[q], 1u);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256)
+    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) {
+      l_take[i] = 0xFFFFFFFFu;
       if (l_cnt[i]) {
         const uint32_t h = l_key[i];
-        if (fix_row_eligible(dir[h], cnt[h])) l_cnt[i] = (uint32_t)excl[pos_of[h]] + atomicAdd(&cursor[h], l_cnt[i]);   // -> this workgroup's first position
+        const DirSlot d = dir[h];
+        if (fix_row_partial(d, cnt[h])) {
+          // the row's first FIX_PART_OPS ops (in the order the workgroups arrive) are the path's, the others go back
+          const uint32_t start = atomicAdd(&cursor[h], l_cnt[i]);
+          const uint32_t take = start < FIX_PART_OPS ? min(l_cnt[i], FIX_PART_OPS - start) : 0u;
+          l_take[i] = take;
+          if (take < l_cnt[i]) l_over[i] = atomicAdd(&l_nback, l_cnt[i] - take);
+          l_cnt[i] = (uint32_t)excl[pos_of[h]] + start;
+        } else if (fix_row_eligible(d, cnt[h])) l_cnt[i] = (uint32_t)excl[pos_of[h]] + atomicAdd(&cursor[h], l_cnt[i]);   // -> this workgroup's first position
         else l_cnt[i] = BACK | atomicAdd(&l_nback, l_cnt[i]);                                                            // (a workgroup holds < 2^31 ops)
       }
+    }
     __syncthreads();
     if (threadIdx.x == 0 && l_nback) l_bbase = atomicAdd(&ctl->n_defer, l_nback);
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < FIXC_OPT; k++) {
       if (hb[k] == FIX_NONE) continue;
-      const uint32_t at = l_cnt[qb[k]], j = defer[t0 + k * 256u + threadIdx.x];
-      if (at & BACK) defer_out[l_bbase + (at & ~BACK) + rk[k]] = j;
+      const uint32_t at = l_cnt[qb[k]], j = defer[t0 + k * 256u + threadIdx.x], take = l_take[qb[k]];
+      if (take != 0xFFFFFFFFu && rk[k] >= take) defer_out[l_bbase + l_over[qb[k]] + (rk[k] - take)] = j;    // a partial row's surplus
+      else if (take == 0xFFFFFFFFu && (at & BACK)) defer_out[l_bbase + (at & ~BACK) + rk[k]] = j;
       else grouped[at + rk[k]] = j;
     }
     __syncthreads();
@@ -1668,14 +1755,15 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
   for (uint32_t ri = wave; ri < nrows; ri += nwaves) {                                    // wave-uniform
     {
       const uint32_t h = touched[ri];
-      const uint32_t c = cnt[h];
-      if (c == 0) continue;                                         // the other pass has taken it
+      const uint32_t c_all = cnt[h];
+      if (c_all == 0) continue;                                     // the other pass has taken it
       const DirSlot d = dir[h];
       const uint64_t e = excl[ri];
       const uint32_t p0 = (uint32_t)e;
       const uint32_t lg0 = meta_lg(d.meta);
-      const uint32_t lgb = fix_bound_lg(d.used, c, lg0);
-      if (!fix_row_eligible(d, c)) {
+      const bool partial = fix_row_partial(d, c_all);               // the row's first ops only, up to 2^FIX_MAX_LG cells (see fix_row_partial)
+      const uint32_t lgb = partial ? FIX_MAX_LG : fix_bound_lg(d.used, c_all, lg0);
+      if (!partial && !fix_row_eligible(d, c_all)) {
         // not for this path: k_fix_scatter has sent the row's ops back to the round loop already (the first pass,
         // which always runs, clears the row's count)
         if (MAXLG == FIX_MAX_LG - 1 && lane == 0) { cnt[h] = 0; cursor[h] = 0; }
@@ -1684,12 +1772,14 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
       if (MAXLG == FIX_MAX_LG ? lgb != FIX_MAX_LG : lgb == FIX_MAX_LG) continue;         // the other pass's row
       wsync();
       if (lane == 0) { cnt[h] = 0; cursor[h] = 0; }                 // taken; and both arrays are all-zero again for the next batch
+      const uint32_t c = partial ? min(c_all, FIX_PART_OPS) : c_all;    // the ops this wave has in `grouped`
+      bool handed_back = false;
       uint32_t cur = 0;                                             // which of the two LDS tables is live
       uint64_t* cells = row_cells(arena, d.base);
       uint32_t lg = lg0, used = d.used;
       for (uint32_t i = lane; i < (1u << lg); i += 64) l_tab[w][0][i] = cells[i];
       wsync();
-      for (uint32_t c0 = 0; c0 < c; c0 += 64) {
+      for (uint32_t c0 = 0; c0 < c && !handed_back; c0 += 64) {
         // this lane's op of the chunk; its result ends up in `res`
         uint32_t j = 0, Yl = 0, Vl = 0, res = 0;
         if (c0 + lane < c) {
@@ -1739,6 +1829,19 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
           used += (uint32_t)__popcll(__ballot(inserted));
           wsync();
           if (!__any(go) && __any(pending)) {
+            if (partial && lg == MAXLG) {
+              // a partial row has reached 2^FIX_MAX_LG cells at the reference's threshold: the ops that are left -- this
+              // chunk's pending ones and the chunks behind it -- go back to the round loop, which doubles the row on
+              const uint64_t pm = __ballot(pending);
+              const uint32_t np = (uint32_t)__popcll(pm), rest = c - min(c0 + 64u, c);
+              uint32_t at = 0;
+              if (lane == 0) at = atomicAdd(&ctl->n_defer, np + rest);
+              at = (uint32_t)__shfl((int)at, 0);
+              if (pending) defer_out[at + (uint32_t)__popcll(pm & lt)] = j;
+              for (uint32_t i = lane; i < rest; i += 64) defer_out[at + np + i] = grouped[p0 + c0 + 64u + i];
+              handed_back = true;
+              break;
+            }
             // ---- smatrix_rmap_resize (src/smatrix.c:383-416): S -> 2S, old slot order
             uint64_t* N = l_tab[w][cur ^ 1u];
             const uint32_t nmask = 2u * S - 1u;
@@ -1797,7 +1900,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_fix_rows(
             lg++;
           }
         }
-        if (c0 + lane < c) out[j] = res;
+        if (c0 + lane < c && !pending) out[j] = res;                  // (handed-back ops get their results from the round loop)
       }
       uint64_t* T = l_tab[w][cur];
       uint64_t* dst = cells;

@@ -548,6 +548,7 @@ struct Matrix {
   bool bulk_enabled = true;             // SMATRIX_BULK=0 switches it off
   bool expect_bulk = true;              // an empty matrix creates its rows: expect it
   uint32_t fix_share = 4;               // ... and only when at least 1/fix_share of the batch is pending (SMATRIX_BULK_SHARE)
+  uint32_t fix_presize_min = 1u << 18;  // deferred ops from which the rows to create are counted first (SMATRIX_BULK_PRESIZE_MIN; ~0: never)
   uint32_t fix_min = 1u << 14;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN): its fixed cost is ~6 small
                                         // launches and 3 read-backs, about two rounds of the loop it replaces
   DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped;
@@ -870,6 +871,33 @@ template <int OP>
 uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out, const uint32_t* x, const uint32_t* y,
                     const uint32_t* v, uint32_t* out, hipStream_t s) {
   // 1. the rows (directory growth included) -- prep without its growth decisions
+  // (round 4) a list that may not fit the directory: its missing rows are counted first and the directory is sized ONCE
+  // (k_fix_count_rows), instead of running the creation pass into "directory full" once per factor of four
+  // (only when the list dwarfs the directory -- the first batches of a matrix; a bulk load in progress, whose directory has
+  //  grown with its rows, keeps the cheap path: one creation pass, now and then a rebuild)
+  if (nd >= m->fix_presize_min && nd / 16 >= m->dir_size) {
+    uint64_t slots = 1u << 16;
+    while (slots < 2ull * std::min<uint64_t>(nd, 1ull << 27)) slots <<= 1;
+    m->cold_set.need(slots);
+    zero_async(m->cold_set.p, slots * 8, s);
+    HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 8, s));
+    hipLaunchKernelGGL(k_fix_count_rows, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXR_OPT), 4096)), dim3(256), 0, s, m->d_dir, m->dir_size - 1, nd, dl,
+                       x, m->in_stride, m->cold_set.p, slots - 1, m->d_small + 12);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    const uint64_t need = (uint64_t)m->dir_used + m->h_small[12] + m->h_small[13];
+    // the size the old one-factor-at-a-time growth would have ended at: x4 while the rows do not fit half the slots, x2
+    // when they fill half of them afterwards
+    uint64_t size = m->dir_size;
+    while (need > size / 2) size *= 4;
+    if (need * 2 >= size) size *= 2;
+    if (m->trace_rounds)
+      fprintf(stderr, "[smatrix] batch %llu bulk path: %u ops name %u rows the directory lacks; directory %u -> %llu slots\n",
+              (unsigned long long)m->st.batches, nd, m->h_small[12] + m->h_small[13], m->dir_size, (unsigned long long)size);
+    if (size > m->dir_size) grow_directory(m, (uint32_t)(size / m->dir_size), s);
+    m->cold_set.release();
+  }
   for (int tries = 0;; tries++) {
     if (tries > 40) smx_die("bulk path: the directory does not take the batch's rows");
     const uint32_t dir_limit = m->dir_size / 2;
@@ -1489,6 +1517,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipHostMalloc(&m->h_small, 64));
   HIP_OK(hipHostMalloc(&m->h_row, 32 + (size_t)SCALAR_ROW_PAIRS_ALLOC * 8));
   if (const char* a = getenv("SMATRIX_SET_LOCATE")) m->set_always_locate = *a == '1';
+  if (const char* a = getenv("SMATRIX_BULK_PRESIZE_MIN")) m->fix_presize_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_FLUSH_SNAPSHOT_MB")) m->flush_snapshot = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE")) m->cache.enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE_CAP")) m->cache.shard_cap = std::max<size_t>(4, std::min<size_t>(strtoull(a, nullptr, 10), CellCache::SLOTS / 2));   // (tests: constant recycling)
