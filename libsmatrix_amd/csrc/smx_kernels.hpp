@@ -1673,7 +1673,10 @@ __global__ __launch_bounds__(256) void k_fix_scatter(Ctl* ctl, const DirSlot* di
         const DirSlot d = dir[h];
         if (fix_row_partial(d, cnt[h])) {
           // the row's first FIX_PART_OPS ops (in the order the workgroups arrive) are the path's, the others go back
-          const uint32_t start = atomicAdd(&cursor[h], l_cnt[i]);
+          // (a look first: the hottest rows are named by every workgroup, and once their quota is taken nobody has to queue
+          //  on the cursor word any more -- it only grows, a stale value merely sends the workgroup to the add)
+          const uint32_t seen = __hip_atomic_load(&cursor[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t start = seen >= FIX_PART_OPS ? seen : atomicAdd(&cursor[h], l_cnt[i]);
           const uint32_t take = start < FIX_PART_OPS ? min(l_cnt[i], FIX_PART_OPS - start) : 0u;
           l_take[i] = take;
           if (take < l_cnt[i]) l_over[i] = atomicAdd(&l_nback, l_cnt[i] - take);
@@ -2672,6 +2675,11 @@ __global__ __launch_bounds__(256) void k_set_store_e(uint32_t n_ent, const uint3
 //  plain stores to one word are not reconciled by a kernel boundary on this chip: two representatives per key, ~100
 //  wrong cells per 1.5 M-op Zipf batch, caught by tests/soak.py), and with agent-scope atomic stores the passes cost
 //  3.5 ms per 2^24 sets against 2.6 for the four below.  DESIGN.md "Measured and rejected".)
+
+// the deferred list of a batch into an EMPTY matrix: every op, in order (run_write)
+__global__ __launch_bounds__(256) void k_iota(uint32_t* out, uint32_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
+}
 
 // ---- directory growth -----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dir_rehash(const DirSlot* old, uint32_t old_size,

@@ -1032,9 +1032,16 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     ctl_read(m, s);
     m->st.rounds++;
     const Ctl& c = *m->h_ctl;
-    if (m->trace_rounds)
-      fprintf(stderr, "[smatrix] batch %llu cold round %u: keys=%u deferred=%u grow=%u (%llu units) rebal=%u dir_full=%u rows=%u\n",
-              (unsigned long long)m->st.batches, round, cur_n, c.n_defer, c.n_tasks, (unsigned long long)c.grow_units, c.n_rebal, c.dir_full, c.dir_used);
+    if (m->trace_rounds) {
+      static thread_local double t_prev = 0;
+      struct timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+      fprintf(stderr, "[smatrix] batch %llu cold round %u (+%.3f ms): keys=%u deferred=%u grow=%u (%llu units) rebal=%u dir_full=%u rows=%u\n",
+              (unsigned long long)m->st.batches, round, t_prev ? now - t_prev : 0.0, cur_n, c.n_defer, c.n_tasks, (unsigned long long)c.grow_units,
+              c.n_rebal, c.dir_full, c.dir_used);
+      t_prev = now;
+    }
     if (c.arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = c.n_defer;
     if (nd == 0) break;
@@ -1110,6 +1117,16 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     const uint64_t est_gu = m->spec_tiny ? 24u : std::max<uint64_t>(2 * m->spec_gu_prev, 1ull << 20);
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room) + (chained ? est_gu : 0), s);
     ctl_reset_round(m, s);
+    // a large write batch into an EMPTY matrix: no row exists, so round 0 of the op kernel would defer every single op
+    // (0.45 ms per 2^24 ops to find that out): the deferred list is the batch itself, in order, and the bulk path takes over
+    const bool all_new = round == 0 && !chained && m->dir_used == 0 && m->bulk_enabled && m->expect_bulk && n >= m->fix_min &&
+                         n >= m->agg_min && m->dbg_after == 0;
+    if (all_new) {
+      hipLaunchKernelGGL(k_iota, dim3(std::min<uint32_t>(blocks_for(n), 4096)), dim3(256), 0, s, dl, n);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipMemcpyAsync(&m->d_ctl->n_defer, &n, 4, hipMemcpyHostToDevice, s));
+      timed0 = false;
+    } else
     launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
     DBG_STEP(m, s, m->long_probes ? "op kernel (lane per op)" : "op kernel");
 #if defined(SMX_AGG_DBG) && SMX_AGG_DBG == 5
