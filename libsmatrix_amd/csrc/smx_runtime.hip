@@ -505,6 +505,11 @@ struct Matrix {
   // retry rounds hold mostly distinct new keys and are small: the one-op-per-lane kernel spreads them
   // over many more workgroups (measured: +4.5 % on config 2 with the threshold at 3e5..2e6)
   uint32_t agg_min_retry = 1u << 20;
+  // ... but only for lists of keys that wait for a row to DOUBLE.  A list the bulk path handed back, or one whose rows did
+  // not exist a round ago, holds the batch's own ops, duplicates and all: 587 000 incr(5, 0, 1) of a 2^20-op batch went lane
+  // by lane through the column-0 compare-and-swap loop (quirk Q1) on ONE cell -- minutes instead of milliseconds (round 4:
+  // found when the bulk path's hand-back fell just below 2^20 ops; round 3's batches sat at the threshold by luck)
+  bool retry_may_repeat = false;
   bool profile = false;
   bool trace_rounds = false;            // SMATRIX_TRACE_ROUNDS=1: one stderr line per round
   bool trace_sync = false;              // SMATRIX_TRACE_ROUNDS=2: ... and a stream sync + a line after every launch (DBG_STEP)
@@ -724,11 +729,11 @@ void launch_apply_op(Matrix* m, int op, hipStream_t s, uint32_t n, const uint32_
       }
       break;
     case OP_INCR:
-      if (!m->long_probes && n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
+      if (!m->long_probes && n >= (idx && !m->retry_may_repeat ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
       else launch_apply<OP_INCR>(m, s, n, idx, x, y, v, out, defer);
       break;
     case OP_DECR:
-      if (!m->long_probes && n >= (idx ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
+      if (!m->long_probes && n >= (idx && !m->retry_may_repeat ? m->agg_min_retry : m->agg_min)) launch_apply_agg<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
       else launch_apply<OP_DECR>(m, s, n, idx, x, y, v, out, defer);
       break;
     default: smx_die("bad op code");
@@ -1085,6 +1090,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   bool timed0 = m->profile;
   uint32_t stalled = 0, rows_before = m->dir_used;
   m->long_probes = false;
+  m->retry_may_repeat = false;
   uint32_t rounds_this_batch = 0;
   bool cold_tried = false;
   bool structure_stable = false;        // round 0 completed the batch: no row was created or doubled (set: the fold's cell addresses hold)
@@ -1162,6 +1168,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
           fprintf(stderr, "[smatrix] batch %llu bulk path: %u deferred ops grouped by row, %u handed back, rows=%u\n",
                   (unsigned long long)m->st.batches, nd0, nd2, m->dir_used);
         if (nd2 == 0) break;
+        m->retry_may_repeat = true;      // (the batch's own ops: y = 0 ops, the hot rows' surplus)
         idx = dl2;                       // what was handed back sits in defer[1]: the next round must write defer[0],
         cur_n = nd2;                     // so it is numbered 2
         round++;
@@ -1287,6 +1294,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
     stalled = progress ? 0 : stalled + 1;
+    m->retry_may_repeat = m->dir_used != rows_before;        // ops of rows that did not exist were deferred whatever their key
     rows_before = m->dir_used;
     m->st.deferred_ops += nd;
     if (round == 0) {

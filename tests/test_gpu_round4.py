@@ -196,3 +196,30 @@ def test_flush_does_not_stall_the_callers(G, oracle_mod, monkeypatch, tmp_path):
     got = o.apply(0, qx.cpu().numpy().view(np.uint32), qy.cpu().numpy().view(np.uint32))
     assert (got == want).all()
     o.close()
+
+
+@pytest.mark.parametrize("n", [(1 << 19) + 12345, (1 << 20) - 1000])
+def test_hot_column_zero_cell_in_a_retry_list_below_the_fold_threshold(G, n):
+    """Round 4: retry lists below 2^20 ops ran lane per op (SMATRIX_AGG_MIN_RETRY: lists of keys that wait for a doubling are
+    mostly distinct).  But a list whose rows did not exist a round ago -- or that the bulk path handed back -- holds the
+    batch's own ops: 60 % of them incr(x, 0, 1) on ONE cell here (the CF example's per-item total,
+    examples/cf_recommender.c:38), which then took the column-0 compare-and-swap loop of quirk Q1 one lane at a time:
+    minutes for half a million ops.  Such lists are folded like round 0 now.  Exact totals, in well under a second."""
+    rng = np.random.default_rng(n)
+    x = rng.choice(np.array([5, 6, 1000003], np.uint32), n, p=[0.75, 0.2, 0.05]).astype(np.uint32)
+    y = np.where(rng.random(n) < 0.8, 0, rng.integers(1, 50000, n)).astype(np.uint32)
+    for first_small in (False, True):
+        g = G()
+        if first_small:
+            g.apply(2, np.array([5], np.uint32), np.array([1], np.uint32), np.array([1], np.uint32))   # row 5 exists, the others do not
+        t0 = time.time()
+        g.apply(2, x, y, np.ones(n, np.uint32))
+        dt = time.time() - t0
+        for item in (5, 6, 1000003):
+            assert g.get(item, 0) == int(((x == item) & (y == 0)).sum())
+        k = (x.astype(np.uint64) << 32 | y)[y != 0]
+        uk, cnt = np.unique(k, return_counts=True)
+        want = cnt + ((uk == ((5 << 32) | 1)) & first_small)
+        assert (g.apply(0, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32)) == want).all()
+        assert dt < 5.0, "%.1f s for %d ops with a hot column-0 cell" % (dt, n)
+        g.close()
