@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Turns the raw outputs of tools/refresh_profiles.sh (gpurun_out/prof_*) into the files committed under profiles/:
-r03_bench.json, r03_rocprof_kernel_stats.txt, r03_pmc_summary.txt, pmc.json (keyed to the kernel source hash), r03_getrow_config3.txt."""
+r04_bench.json (the full result; the stdout line is its short form), r04_rocprof_kernel_stats.txt, r04_pmc_summary.txt, pmc.json
+(keyed to the kernel source hash), r04_getrow_config3.txt, r04_floor.txt."""
 import hashlib, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = "r03"
+RND = "r04"
 
 
 def kernel_source_sha16():
@@ -36,7 +37,7 @@ rd_agg = agg["miss"] - agg["atom"]
 t_agg = rd_agg / (R * 1e9) + agg["atom"] / (A * 1e9); t_get = get["miss"] / (R * 1e9)
 ki, kg = b["roofline"]["avg_launch_ms"], b["roofline_get"]["avg_launch_ms"]
 hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --no-cpu --no-extras   (three separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; tools/refresh_profiles.sh + tools/build_profiles.py)
-# MI355X, round 3, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
+# MI355X, round 4, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
 # Calibration in our own access pattern, same runs: k_probe_random<0> = 2^27 random 8-byte loads over 4 GiB -> %.0f KiB = %.1f B per touch
 #   (a 64 B line per touch; no 1/2 correction for this shape); k_probe_random<1>/<2> = 2^27 scattered 32-bit atomics -> WRITE_SIZE 32 B and TCC_EA0_ATOMIC 1.0 per atomic.
 #   (the guide's gfx950 correction -- FETCH_SIZE tallies a 128-B coalesced streaming request at 64 B -- applies only to the streamed op arrays,
@@ -68,7 +69,7 @@ json.dump({"summary": "profiles/%s_pmc_summary.txt" % RND, "kernel_source_sha16"
                            "l2_misses": get["miss"]}}, open(os.path.join(P, "pmc.json"), "w"), indent=1)
 ur = json.load(open(os.path.join(G, "prof_bench_under_rocprof.json")))
 open(os.path.join(P, RND + "_rocprof_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 3, tools/refresh_profiles.sh; bench line of this "
+    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 4, tools/refresh_profiles.sh; bench line of this "
     "same profiled run: %.0f Mops/s, k_apply_agg<INCR> round-0 avg %.3f ms and k_apply<GET> %.3f ms by HIP events; the full-batch grids below include the 4 all-hit "
     "replays of the steady-state extra and the first batches of the empty table)\n" % (ur["value"], ur["roofline"]["avg_launch_ms"], ur["roofline_get"]["avg_launch_ms"])
     + open(os.path.join(G, "prof_kernel_stats.txt")).read()
@@ -95,8 +96,8 @@ def val3(kern, ctr):
 
 
 f3, w3 = val3("smx::k_getrow", "FETCH_SIZE"), val3("smx::k_getrow", "WRITE_SIZE")
-d3 = c3["detail"]
-lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 3" % (d3["rows"], d3["nnz"]),
+d3 = c3["result"]
+lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 4" % (d3["rows"], d3["nnz"]),
          "# bench line of the profiled run: getrow %.3f ms = %.1f G nnz/s; algorithmic %.0f GB/s = %.3f of the 8 TB/s peak; build %.2f s (%.2f G ops/s)"
          % (d3["getrow_ms"], d3["Gnnz_per_s"], d3["roofline"]["achieved"], d3["roofline"]["frac"], d3["build_s"], d3["build_Gops_per_s"])]
 if f3 and w3:
@@ -111,3 +112,63 @@ if f3 and w3:
     json.dump(pj, open(os.path.join(P, "pmc.json"), "w"), indent=1)
 open(os.path.join(P, RND + "_getrow_config3.txt"), "w").write("\n".join(lines) + "\n" + ks3 + "\n" + raw3)
 json.dump(c3, open(os.path.join(P, RND + "_bench_config3.json"), "w"))
+
+# ---- the floor of the mixed step: fresh PMC counts x the probe rates of the same box, not prose
+spans = open(os.path.join(G, "prof_step_spans.txt")).read()
+tl = open(os.path.join(G, "prof_timeline_step23.txt")).read()
+growth_us = 0.0
+names = []
+for ln in tl.splitlines():
+    m = re.match(r"\s*([\d.]+) us\s+\+\s*([\d.]+)\s+(\S+)", ln)
+    if m and not m.group(3).startswith("smx::k_apply_agg") and m.group(3) != "smx::k_apply<0>" and "copyBuffer" not in m.group(3):
+        names.append((m.group(3), float(m.group(2))))
+# critical path of the growth round: prep, plan, the longer of {three in-LDS rehash kinds in sequence} and {map, move, finish, zero on the
+# helper stream}, commit, advance, retry, prep
+def dur(prefix):
+    return sum(v for k, v in names if k.startswith(prefix))
+lds = dur("smx::k_grow_lds")
+chunked = dur("smx::k_grow_map") + dur("smx::k_grow_move") + dur("smx::k_grow_finish") + dur("smx::k_grow_zero")
+crit = dur("smx::k_prep") + dur("smx::k_grow_plan") + max(lds, chunked) + dur("smx::k_grow_commit") + dur("smx::k_round_advance") + dur("smx::k_apply<2>")
+steady = b.get("steady_state_all_hits", {})
+ins = agg["atom"] - 15.0e6                                           # tickets + claims beyond one atomic per (tile, key) entry (census: 15.0 M entries)
+floor_agg = t_agg * 1e3
+floor_get = t_get * 1e3
+lines_f = [
+ "# The floor of one mixed step (incr batch + get batch of 2^24 ops each, config 2) of THIS design on THIS box -- round 4.",
+ "# Every count is a PMC mean of the committed passes (profiles/%s_pmc_summary.txt), every rate a probe of the same bench run" % RND,
+ "# (random_access in profiles/%s_bench.json); nothing here is estimated from prose." % RND,
+ "",
+ "chip rates (uniform random over 4 GiB): read8 %.1f G/s, returning atomic %.1f G/s" % (R, A),
+ "",
+ "k_apply_agg<INCR>, one launch = 2^24 ops:",
+ "  memory-side atomics (TCC_EA0_ATOMIC)        %6.2f M   / %.1f G/s = %.3f ms" % (agg["atom"] / 1e6, A, agg["atom"] / (A * 1e9) * 1e3),
+ "  read misses (TCC_MISS - atomics)            %6.2f M   / %.1f G/s = %.3f ms" % (rd_agg / 1e6, R, rd_agg / (R * 1e9) * 1e3),
+ "  transaction floor                                                     %.3f ms   (measured %.3f ms by HIP events: %.0f %% of the floor's rate)" % (floor_agg, ki, 100 * floor_agg / ki),
+ "k_apply<GET>, one launch = 2^24 ops:",
+ "  read misses (TCC_MISS)                      %6.2f M   / %.1f G/s = %.3f ms   (measured %.3f ms)" % (get["miss"] / 1e6, R, floor_get, kg),
+ "growth round of a steady batch (kernel timeline of step 23 of the same trace, critical path):",
+ "  prep %.0f + plan %.0f + max(in-LDS rehash x3 %.0f, chunked passes %.0f) + commit %.0f + advance %.0f + retry %.0f us = %.3f ms"
+ % (dur("smx::k_prep"), dur("smx::k_grow_plan"), lds, chunked, dur("smx::k_grow_commit"), dur("smx::k_round_advance"), dur("smx::k_apply<2>"), crit / 1e3),
+ "",
+ "floor of the step with every kernel AT its transaction floor and no idle time:  %.3f + %.3f + %.3f = %.3f ms" % (floor_agg, floor_get, crit / 1e3, floor_agg + floor_get + crit / 1e3),
+ "measured: %.3f ms per step over the timed steps (%.2f G mixed ops/s); all-hit replay %.3f ms" % (b["ms_per_step"], b["value"] / 1e3, steady.get("ms_per_step", float("nan"))),
+ "target of north_star: 0.40 of read8 = %.3f ms per step" % (2 * N / (0.4 * R * 1e9) * 1e3),
+ "",
+ "What the counts are made of (tools/probe/insert_census.py + tile_fold_census.py, batch 15 of the stream, CPU):",
+ "  14.99 M (tile, key) entries for 7.01 M distinct keys: one verify load + one returning atomic each; 3.74 M of them are inserts",
+ "  (+ one `used` ticket each, + the claim CAS instead of the add).  95.6 % of the entries have ONE op in their tile (85 % of the ops):",
+ "  the LDS fold removes the hot cells' serialisation, not transactions.  6.07 M of the 7.01 M keys appear in one tile only; the 0.94 M",
+ "  keys that appear in several tiles make up 8.92 M entries -- what a cross-tile fold would save, priced in rounds 2/3 at >= its own cost",
+ "  on one GPU (a 1024-way key split + the un-permuting of results).",
+ "  Ticket-free inserts (VERDICT r3 2b): 90.0 % of the inserts land in rows whose room covers the row's TRUE number of new keys, 73.5 % in rows",
+ "  whose room covers the row's OP COUNT in the batch -- the only bound a kernel could hold, and computing it (a per-batch row histogram)",
+ "  costs one atomic per (tile, row) pair, ~10 M per batch against the 3.7 M tickets it would save.  Estimates from the previous batch cover",
+ "  39-70 % but are not bounds: one row that overshoots its threshold breaks the reference's growth rule (src/smatrix.c:343-360).  Dropped.",
+ "  Hot/cold split (2c): the whole LDS fold costs 0.14 ms of the kernel (profiles/r02_agg_kernel_phase_shares.txt) and the kernel already runs",
+ "  8 waves per SIMD (two 1024-lane workgroups per CU): there is no third workgroup to win, whatever the table costs.  Dropped.",
+ "  Round >= 1 in one launch (2a): the growth round's critical path above is kernel time, ~%.2f ms; grouping the ~230 000 deferred ops by row" % (crit / 1e3),
+ "  (count, scan, scatter, rows) is five launches of its own -- round 2 measured that fixed cost at what the round costs today.  The bulk",
+ "  path was widened where it pays instead: hot rows now give it their first 2048 ops (cold start 13.4 -> 10.5 ms).",
+]
+open(os.path.join(P, RND + "_floor.txt"), "w").write("\n".join(lines_f) + "\n")
+print("\n".join(lines_f))

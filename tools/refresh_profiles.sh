@@ -5,15 +5,19 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/prof_bench.json 2> $O/prof_bench.err
+# (bench.py prints the SHORT line; the full result -- what tools/build_profiles.py reads -- is bench_detail.json)
+python3 $R/bench.py > $O/prof_bench_line.json 2> $O/prof_bench.err
+cp $R/bench_detail.json $O/prof_bench.json
 # config 2: kernel stats + spans + timeline
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu --no-extras > $O/prof_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu --no-extras > /dev/null 2>&1
+cp $R/bench_detail.json $O/prof_bench_under_rocprof.json
 python3 $R/tools/prof_summary.py $O/kt $O/prof_kernel_stats.txt
 python3 $R/tools/step_spans.py $O/kt > $O/prof_step_spans.txt
 python3 $R/tools/timeline.py $O/kt 23 > $O/prof_timeline_step23.txt
 rm -rf $O/kt
 # config 3: kernel stats of the getrow scan
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python3 $R/bench.py --config 3 > $O/prof_bench_config3_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python3 $R/bench.py --config 3 > /dev/null 2>&1
+cp $R/bench_detail_config3.json $O/prof_bench_config3_under_rocprof.json
 python3 $R/tools/prof_summary.py $O/kt3 $O/prof_kernel_stats_config3.txt
 rm -rf $O/kt3
 # PMC passes (one counter set per run)
