@@ -563,6 +563,7 @@ struct Matrix {
   bool spec_enabled = true;             // SMATRIX_SPEC=0 switches it off
   bool spec_ready = false;
   bool spec_tiny = false;               // SMATRIX_SPEC_TINY=1 (tests)
+  uint32_t last_nd0 = 1;                // ops the previous write batch deferred in its round 0 (0: the next batch is not chained)
   uint32_t spec_nd_prev = 0, spec_nt_prev = 0, spec_nk_prev[4] = {0, 0, 0, 0};   // the previous batch's round 0: deferred ops, growth tasks (by kind)
   uint64_t spec_gu_prev = 0;            // ... and the units its growths took
   bool long_probes = false;             // this batch: the folding kernel set ops aside for the wave-cooperative probe -> retries run lane-per-op
@@ -1095,7 +1096,11 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   bool cold_tried = false;
   bool structure_stable = false;        // round 0 completed the batch: no row was created or doubled (set: the fold's cell addresses hold)
   // the chain is tried when the previous write batch was finished by its round 1 (or by the chain itself)
-  bool chain = m->spec_enabled && m->spec_ready && !m->expect_bulk && n >= m->agg_min && m->dbg_after == 0;
+  // ... and deferred something in its round 0: on a table that takes a batch without a single deferred op -- every key present,
+  // or inserted with room to spare -- the chain's dozen launches run empty (65-70 us of a 1.8 ms all-hit step, round 4 trace);
+  // such batches go op kernel, prep, read-back, and the first one that defers again is finished by the host-driven loop
+  bool chain = m->spec_enabled && m->spec_ready && !m->expect_bulk && n >= m->agg_min && m->dbg_after == 0 &&
+               (m->last_nd0 != 0 || m->spec_tiny);
   for (uint32_t round = 0;; round++) {
     // the loop ends when nothing is deferred; it is abandoned only when rounds stop making PROGRESS (a fixed cap
     // would turn a slow but legal batch -- many new rows contending for one directory slot -- into an abort)
@@ -1238,6 +1243,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       // bookkeeping of the round the host did not see, then on as if round 1 had just been read back
       const Ctl& c = *m->h_ctl;
       nd_chain0 = c.spec_nd0;
+      if (!m->in_cache_sync) m->last_nd0 = nd_chain0;
       m->expect_bulk = (uint64_t)nd_chain0 * 8 >= n;
       m->st.spec_chains++;
       if (nd_chain0) {
@@ -1281,6 +1287,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const uint32_t nd = m->h_ctl->n_defer;
     if (round == 0) m->expect_bulk = (uint64_t)nd * 8 >= n;
+    if (round == 0 && !chained && !m->in_cache_sync) m->last_nd0 = nd;
     if (round == 1 && !chained && nd == 0) {
       // the steady shape: remember what round 0 needed -- the next batch's chain is sized from it
       m->spec_nd_prev = cur_n;

@@ -74,7 +74,7 @@ open(os.path.join(P, RND + "_rocprof_kernel_stats.txt"), "w").write(
     "replays of the steady-state extra and the first batches of the empty table)\n" % (ur["value"], ur["roofline"]["avg_launch_ms"], ur["roofline_get"]["avg_launch_ms"])
     + open(os.path.join(G, "prof_kernel_stats.txt")).read()
     + "\n# per-step spans of the same trace (tools/step_spans.py): span, busy, idle, kernels, prep rounds | top kernels (us)\n"
-    + open(os.path.join(G, "prof_step_spans.txt")).read() + "\n# kernel timeline of step 23 (tools/timeline.py)\n"
+    + open(os.path.join(G, "prof_step_spans.txt")).read() + "\n# kernel timeline of the last step of the growing table (tools/timeline.py <dir> last-growing)\n"
     + open(os.path.join(G, "prof_timeline_step23.txt")).read())
 # the bench line must carry the traffic of THIS refresh: bench.py reads profiles/pmc.json, which was just rewritten
 b["roofline"]["traffic"] = int(bytes_agg); b["roofline_get"]["traffic"] = int(bytes_get)
@@ -146,7 +146,7 @@ lines_f = [
  "  transaction floor                                                     %.3f ms   (measured %.3f ms by HIP events: %.0f %% of the floor's rate)" % (floor_agg, ki, 100 * floor_agg / ki),
  "k_apply<GET>, one launch = 2^24 ops:",
  "  read misses (TCC_MISS)                      %6.2f M   / %.1f G/s = %.3f ms   (measured %.3f ms)" % (get["miss"] / 1e6, R, floor_get, kg),
- "growth round of a steady batch (kernel timeline of step 23 of the same trace, critical path):",
+ "growth round of a steady batch (kernel timeline of the last growing step of the same trace, critical path):",
  "  prep %.0f + plan %.0f + max(in-LDS rehash x3 %.0f, chunked passes %.0f) + commit %.0f + advance %.0f + retry %.0f us = %.3f ms"
  % (dur("smx::k_prep"), dur("smx::k_grow_plan"), lds, chunked, dur("smx::k_grow_commit"), dur("smx::k_round_advance"), dur("smx::k_apply<2>"), crit / 1e3),
  "",

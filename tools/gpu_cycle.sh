@@ -10,5 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/kt -- python3 $R/bench.py --no-cpu --no-extras --no-profile | python3 -c "$P"
 cd $R
 python tools/step_spans.py gpurun_out/kt | tail -8 > gpurun_out/spans.txt
-python tools/timeline.py gpurun_out/kt 23 > gpurun_out/tl23.txt
+python tools/timeline.py gpurun_out/kt last-growing > gpurun_out/tl23.txt
 rm -rf gpurun_out/kt

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/benc
 cp $R/bench_detail.json $O/prof_bench_under_rocprof.json
 python3 $R/tools/prof_summary.py $O/kt $O/prof_kernel_stats.txt
 python3 $R/tools/step_spans.py $O/kt > $O/prof_step_spans.txt
-python3 $R/tools/timeline.py $O/kt 23 > $O/prof_timeline_step23.txt
+python3 $R/tools/timeline.py $O/kt last-growing > $O/prof_timeline_step23.txt
 rm -rf $O/kt
 # config 3: kernel stats of the getrow scan
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python3 $R/bench.py --config 3 > /dev/null 2>&1
