@@ -1,4 +1,4 @@
-"""per-step wall time of the first batches of config 2 (young table): python tools/diag/early_steps.py [n]"""
+"""per-step wall time of the first batches of config 2 (young table): python tools/probe/early_steps.py [n]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,5 +1,5 @@
 """where a bench step's wall time goes on the host: incr call (blocks: the round loop reads counters back), get call
-(asynchronous), final sync.  python tools/diag/step_host_times.py [profile 0/1]"""
+(asynchronous), final sync.  python tools/probe/step_host_times.py [profile 0/1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
