@@ -223,3 +223,66 @@ def test_hot_column_zero_cell_in_a_retry_list_below_the_fold_threshold(G, n):
         assert (g.apply(0, (uk >> 32).astype(np.uint32), (uk & 0xFFFFFFFF).astype(np.uint32)) == want).all()
         assert dt < 5.0, "%.1f s for %d ops with a hot column-0 cell" % (dt, n)
         g.close()
+
+
+def test_flush_in_steps_while_rows_change(G, oracle_mod, monkeypatch, tmp_path):
+    """The snapshot flush under load: a 2 MB snapshot budget makes one smatrix_flush of ~60 MB of dirty tables go out in dozens of
+    steps (k_dirty_collect's budget, the `more` loop, the file index extended step by step), while another thread keeps
+    writing -- values of rows already flushed (rewritten in place by the next flush), new keys that make rows of the flush
+    DOUBLE between its steps (fresh blocks, re-pointed CMAP entries, the old ones leaked as in src/smatrix.c:430-436), brand-new
+    rows.  Every file state a reader can see must be consistent; here: after a final flush the file, read by the oracle AND
+    by this library's loader, equals the matrix cell for cell, rowlen for rowlen."""
+    import threading
+    monkeypatch.setenv("SMATRIX_FLUSH_MS", "0")
+    monkeypatch.setenv("SMATRIX_FLUSH_SNAPSHOT_MB", "2")
+    path = str(tmp_path / "steps.smx")
+    rng = np.random.default_rng(2024)
+    g, o = G(path), oracle_mod.Oracle()
+    rows = 30000
+    x = np.repeat(np.arange(1, rows + 1, dtype=np.uint32) * np.uint32(2654435761), 100)
+    y = (rng.integers(1, 1 << 30, x.size, dtype=np.uint32) | np.uint32(1))
+    v = rng.integers(1, 1000, x.size, dtype=np.uint32)
+    g.apply(2, x, y, v); o.apply(2, x, y, v)
+    stop = threading.Event()
+    log = []
+
+    def writer():
+        r2 = np.random.default_rng(7)
+        k = 0
+        while not stop.is_set() and k < 400:
+            pick = r2.integers(0, rows, 300)
+            xs = (np.arange(1, rows + 1, dtype=np.uint32) * np.uint32(2654435761))[pick]
+            xs = np.concatenate([xs, np.array([0x70000000 + k], np.uint32)])          # ... and a brand-new row
+            xs = np.repeat(xs, 40)
+            ys = (r2.integers(1, 1 << 30, xs.size, dtype=np.uint32) | np.uint32(1))
+            vs = r2.integers(1, 50, xs.size, dtype=np.uint32)
+            g.apply(2, xs, ys, vs)
+            log.append((xs, ys, vs))
+            k += 1
+
+    th = threading.Thread(target=writer)
+    th.start()
+    time.sleep(0.05)
+    g.m.flush()                                            # dozens of steps, the writer in between
+    st_mid = g.stats()
+    stop.set(); th.join()
+    for xs, ys, vs in log:
+        o.apply(2, xs, ys, vs)
+    assert len(log) >= 3, "the writer did not get a word in"
+    g.m.flush()
+    st = g.stats()
+    assert st["file_flushes"] >= 12, st                    # (60 MB in 2 MB steps, then the rest)
+    allx = np.concatenate([x] + [a for a, _, _ in log]); ally = np.concatenate([y] + [b for _, b, _ in log])
+    want = o.apply(0, allx, ally)
+    assert (g.apply(0, allx, ally) == want).all()
+    g.close()
+    f = oracle_mod.Oracle(path)                            # the checker's loader (the reference's load rule, src/smatrix.c:499-545)
+    assert f.num_rows() == o.num_rows()
+    assert (f.apply(0, allx, ally) == want).all()
+    ur = np.unique(allx)
+    assert [f.rowlen(int(r)) for r in ur[:2000]] == [o.rowlen(int(r)) for r in ur[:2000]]
+    f.close()
+    g2 = G(path)                                           # ... and this library's
+    assert g2.stats()["rows"] == o.num_rows()
+    assert (g2.apply(0, allx, ally) == want).all()
+    g2.close(); o.close()
