@@ -286,3 +286,33 @@ def test_flush_in_steps_while_rows_change(G, oracle_mod, monkeypatch, tmp_path):
     assert g2.stats()["rows"] == o.num_rows()
     assert (g2.apply(0, allx, ally) == want).all()
     g2.close(); o.close()
+
+
+def test_many_rows_flushed_in_steps_stay_fast(G, oracle_mod, monkeypatch, tmp_path):
+    """Round 4: a backlog above the snapshot budget goes out in steps, and a step takes its rows in DIRECTORY order -- ids
+    whose fmix32 values form one contiguous range.  The host-side file index hashed row ids with that same fmix32, so a step's
+    rows all fell into one slice of its table (20 probes per insert at 4 M rows, seconds per step at 13 M), and a rebuilt
+    table could come out just under half full, after which every single added row rebuilt it again.  2 M small rows in 16 MB
+    steps (~20 steps of 100 000 rows): the flush must take seconds, and the file must hold every row."""
+    monkeypatch.setenv("SMATRIX_FLUSH_MS", "0")
+    monkeypatch.setenv("SMATRIX_FLUSH_SNAPSHOT_MB", "16")
+    path = str(tmp_path / "many.smx")
+    g = G(path)
+    rows = 2000000
+    x = (np.arange(1, rows + 1, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    y = np.full(rows, 7, np.uint32)
+    v = (np.arange(rows, dtype=np.uint32) % 1000) + 1
+    g.apply(2, x, y, v)
+    assert g.stats()["rows"] == rows
+    t0 = time.time()
+    g.m.flush()
+    dt = time.time() - t0
+    st = g.stats()
+    assert st["file_flushes"] >= 10 and st["file_rows_written"] == rows, st
+    assert dt < 30.0, "%.1f s for %d rows in %d steps" % (dt, rows, st["file_flushes"])
+    g.close()
+    o = oracle_mod.Oracle(path)
+    assert o.num_rows() == rows
+    pick = np.random.default_rng(3).integers(0, rows, 50000)
+    assert (o.apply(0, x[pick], y[pick]) == v[pick]).all()
+    o.close()
