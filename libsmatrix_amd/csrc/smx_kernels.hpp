@@ -572,7 +572,13 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
       d = dir_find(dir, dmask, xs[(size_t)j * st], &s);
       if (!d || s.z == 0) deferred = true;                       // the row does not exist (yet): prep creates it
       else if (Y == 0) general = true;
-      else {
+      else if (meta_lg(s.x) < BIG_LG ? s.w > (1u << meta_lg(s.x)) / 2u
+                                     : __hip_atomic_load(&row_subs(arena, s.z, meta_lg(s.x))[0].pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        // (round 4) the row stands at the reference's threshold (src/smatrix.c:346) -- the snapshot's count, or a big row's
+        // "every share is used up" mark: the key is absent (listed keys are), so it is deferred WITHOUT walking to its empty
+        // cell first.  Three quarters of a cold round's keys belong to rows that are waiting for their doubling.
+        deferred = true;
+      } else {
         mask = (1u << meta_lg(s.x)) - 1u;
         cells = row_cells(arena, s.z);
         if (!(s.x & META_DIRTY)) d->meta = s.x | META_DIRTY;
@@ -1493,17 +1499,21 @@ constexpr uint32_t FIXC_OPT = 8, FIXC_SLOTS = 4096;
 __global__ __launch_bounds__(256) void k_fix_count(Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t n, const uint32_t* defer,
                                                    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t st,
                                                    uint32_t* cnt, uint32_t* where, uint32_t* defer_out, uint32_t* touched,
-                                                   uint32_t* pos_of) {
+                                                   uint32_t* pos_of, uint32_t* rank_of) {
   // touched[0 .. ctl->n_tasks): the directory slots with pending ops (a slot is listed by whoever raises its count from
   // 0), pos_of[h] = its place in that list -- everything after this pass works on that list, not on the directory
+  // rank_of[t] (round 4): the op's place among its row's pending ops -- the add that raises the row's count returns where this
+  // workgroup's share of the row starts, the LDS add the op's place inside the share.  The scatter pass used to fold its
+  // ops by row once more and reserve the same ranges again on a cursor word per row (8 192 workgroups on the hottest rows'
+  // words: 1.5 ms of the first batch of config 2); now it only reads the rank
   __shared__ uint32_t l_key[FIXC_SLOTS], l_cnt[FIXC_SLOTS];
   __shared__ uint32_t l_n, l_base, l_first, l_fbase;
   for (uint32_t t0 = blockIdx.x * 256u * FIXC_OPT; t0 < n; t0 += gridDim.x * 256u * FIXC_OPT) {   // block-uniform
     for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) { l_key[i] = FIX_NONE; l_cnt[i] = 0; }
     if (threadIdx.x == 0) { l_n = 0; l_first = 0; }
     __syncthreads();
-    uint32_t jb[FIXC_OPT], rk[FIXC_OPT];
-    uint32_t backm = 0;
+    uint32_t jb[FIXC_OPT], rk[FIXC_OPT], qb[FIXC_OPT];
+    uint32_t backm = 0, takem = 0;
 #pragma unroll
     for (uint32_t k = 0; k < FIXC_OPT; k++) {
       const uint32_t t = t0 + k * 256u + threadIdx.x;
@@ -1521,7 +1531,9 @@ __global__ __launch_bounds__(256) void k_fix_count(Ctl* ctl, DirSlot* dir, uint3
           if (prev == FIX_NONE || prev == h) break;
           q = (q + 1) & (FIXC_SLOTS - 1);
         }
-        atomicAdd(&l_cnt[q], 1u);
+        qb[k] = q;
+        rk[k] = atomicAdd(&l_cnt[q], 1u);                           // the op's place in this workgroup's share of the row
+        takem |= 1u << k;
       } else {
         where[t] = FIX_NONE;
         backm |= 1u << k;
@@ -1531,15 +1543,21 @@ __global__ __launch_bounds__(256) void k_fix_count(Ctl* ctl, DirSlot* dir, uint3
     __syncthreads();
     uint32_t fh[FIXC_SLOTS / 256], fr[FIXC_SLOTS / 256], nf = 0;     // slots this lane raised from 0: they join the list
     for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256)
-      if (l_cnt[i] && atomicAdd(&cnt[l_key[i]], l_cnt[i]) == 0) { fh[nf] = l_key[i]; fr[nf] = atomicAdd(&l_first, 1u); nf++; }
+      if (l_cnt[i]) {
+        const uint32_t start = atomicAdd(&cnt[l_key[i]], l_cnt[i]);   // where this workgroup's share of the row starts
+        l_cnt[i] = start;
+        if (start == 0) { fh[nf] = l_key[i]; fr[nf] = atomicAdd(&l_first, 1u); nf++; }
+      }
     __syncthreads();
     if (threadIdx.x == 0 && l_n) l_base = atomicAdd(&ctl->n_defer, l_n);
     if (threadIdx.x == 0 && l_first) l_fbase = atomicAdd(&ctl->n_tasks, l_first);
     __syncthreads();
     for (uint32_t k = 0; k < nf; k++) { touched[l_fbase + fr[k]] = fh[k]; pos_of[fh[k]] = l_fbase + fr[k]; }
 #pragma unroll
-    for (uint32_t k = 0; k < FIXC_OPT; k++)
+    for (uint32_t k = 0; k < FIXC_OPT; k++) {
       if (backm & (1u << k)) defer_out[l_base + rk[k]] = jb[k];
+      if (takem & (1u << k)) rank_of[t0 + k * 256u + threadIdx.x] = l_cnt[qb[k]] + rk[k];
+    }
     __syncthreads();
   }
 }
@@ -1635,66 +1653,62 @@ __global__ __launch_bounds__(256) void k_fix_scan_add(const Ctl* ctl, uint64_t* 
   if (i < aload(&ctl->n_tasks)) excl[i] += tile_sum[i / SCAN_TILE];
 }
 
-// pass 3: the op indices, row by row -- the same LDS fold: a workgroup reserves its share of a row's range once
+// pass 3: the op indices, row by row.  Every op knows its place among its row's ops (rank_of, pass 1): ops of eligible rows
+// go to their row's range of `grouped`; of a PARTIAL row (fix_row_partial) the first FIX_PART_OPS; everything else -- a hot row's
+// millions among them -- goes straight back to the round loop's list, one reservation per workgroup (copying them back row by
+// row, one wave per row, took 27 ms for the 4 M ops of one hot item).  No fold and no per-row cursor any more (round 4).
 __global__ __launch_bounds__(256) void k_fix_scatter(Ctl* ctl, const DirSlot* dir, const uint32_t* cnt, uint32_t n, const uint32_t* defer,
-                                                     const uint32_t* where, const uint64_t* excl, const uint32_t* pos_of, uint32_t* cursor,
+                                                     const uint32_t* where, const uint64_t* excl, const uint32_t* pos_of, const uint32_t* rank_of,
                                                      uint32_t* grouped, uint32_t* defer_out) {
-  // ops of eligible rows go to their row's range of `grouped`; ops of the others -- a hot row's millions among them -- go
-  // straight back to the round loop's list, one reservation per workgroup (copying them back row by row, one wave per
-  // row, took 27 ms for the 4 M ops of one hot item)
-  constexpr uint32_t BACK = 0x80000000u;
-  __shared__ uint32_t l_key[FIXC_SLOTS], l_cnt[FIXC_SLOTS];
-  __shared__ uint32_t l_take[FIXC_SLOTS], l_over[FIXC_SLOTS];      // partial rows: ops of this workgroup the path takes; where its other ops go back
   __shared__ uint32_t l_nback, l_bbase;
   for (uint32_t t0 = blockIdx.x * 256u * FIXC_OPT; t0 < n; t0 += gridDim.x * 256u * FIXC_OPT) {   // block-uniform
-    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) { l_key[i] = FIX_NONE; l_cnt[i] = 0; }
     if (threadIdx.x == 0) l_nback = 0;
     __syncthreads();
-    uint32_t hb[FIXC_OPT], qb[FIXC_OPT], rk[FIXC_OPT];
+    uint32_t jb[FIXC_OPT], at[FIXC_OPT];
+    uint32_t backm = 0, takem = 0;
 #pragma unroll
     for (uint32_t k = 0; k < FIXC_OPT; k++) {
       const uint32_t t = t0 + k * 256u + threadIdx.x;
-      hb[k] = t < n ? where[t] : FIX_NONE;
-      if (hb[k] == FIX_NONE) continue;
-      uint32_t q = (hb[k] * 0x9E3779B1u) >> 20;
-      for (;;) {
-        const uint32_t prev = atomicCAS(&l_key[q], FIX_NONE, hb[k]);
-        if (prev == FIX_NONE || prev == hb[k]) break;
-        q = (q + 1) & (FIXC_SLOTS - 1);
-      }
-      qb[k] = q;
-      rk[k] = atomicAdd(&l_cnt[q], 1u);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < FIXC_SLOTS; i += 256) {
-      l_take[i] = 0xFFFFFFFFu;
-      if (l_cnt[i]) {
-        const uint32_t h = l_key[i];
-        const DirSlot d = dir[h];
-        if (fix_row_partial(d, cnt[h])) {
-          // the row's first FIX_PART_OPS ops (in the order the workgroups arrive) are the path's, the others go back
-          // (a look first: the hottest rows are named by every workgroup, and once their quota is taken nobody has to queue
-          //  on the cursor word any more -- it only grows, a stale value merely sends the workgroup to the add)
-          const uint32_t seen = __hip_atomic_load(&cursor[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t start = seen >= FIX_PART_OPS ? seen : atomicAdd(&cursor[h], l_cnt[i]);
-          const uint32_t take = start < FIX_PART_OPS ? min(l_cnt[i], FIX_PART_OPS - start) : 0u;
-          l_take[i] = take;
-          if (take < l_cnt[i]) l_over[i] = atomicAdd(&l_nback, l_cnt[i] - take);
-          l_cnt[i] = (uint32_t)excl[pos_of[h]] + start;
-        } else if (fix_row_eligible(d, cnt[h])) l_cnt[i] = (uint32_t)excl[pos_of[h]] + atomicAdd(&cursor[h], l_cnt[i]);   // -> this workgroup's first position
-        else l_cnt[i] = BACK | atomicAdd(&l_nback, l_cnt[i]);                                                            // (a workgroup holds < 2^31 ops)
+      const uint32_t h = t < n ? where[t] : FIX_NONE;
+      if (h == FIX_NONE) continue;                                    // (pass 1 has sent it back already)
+      jb[k] = defer[t];
+      const DirSlot d = dir[h];
+      const uint32_t c = cnt[h], r = rank_of[t];
+      const bool part = fix_row_partial(d, c);
+      if (part ? r < FIX_PART_OPS : fix_row_eligible(d, c)) {
+        at[k] = (uint32_t)excl[pos_of[h]] + r;
+        takem |= 1u << k;
+      } else {
+        backm |= 1u << k;
       }
     }
+    // the ops that go back: one list reservation per workgroup (a wave's share through one LDS add)
+    const uint32_t mine = (uint32_t)__popc(backm);
+    const uint64_t lanes_before = (1ull << __lane_id()) - 1ull;
+    uint32_t wave_tot = mine, pre = 0;
+    // prefix over the wave (six shuffle steps) -- lanes hold 0..FIXC_OPT ops each
+    {
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (__lane_id() >= (uint32_t)o) incl += up;
+      }
+      pre = incl - mine;
+      wave_tot = (uint32_t)__shfl((int)incl, 63);
+      (void)lanes_before;
+    }
+    uint32_t wbase = 0;
+    if (__lane_id() == 0 && wave_tot) wbase = atomicAdd(&l_nback, wave_tot);
+    wbase = (uint32_t)__shfl((int)wbase, 0);
     __syncthreads();
     if (threadIdx.x == 0 && l_nback) l_bbase = atomicAdd(&ctl->n_defer, l_nback);
     __syncthreads();
+    uint32_t o = l_bbase + wbase + pre;
 #pragma unroll
     for (uint32_t k = 0; k < FIXC_OPT; k++) {
-      if (hb[k] == FIX_NONE) continue;
-      const uint32_t at = l_cnt[qb[k]], j = defer[t0 + k * 256u + threadIdx.x], take = l_take[qb[k]];
-      if (take != 0xFFFFFFFFu && rk[k] >= take) defer_out[l_bbase + l_over[qb[k]] + (rk[k] - take)] = j;    // a partial row's surplus
-      else if (take == 0xFFFFFFFFu && (at & BACK)) defer_out[l_bbase + (at & ~BACK) + rk[k]] = j;
-      else grouped[at + rk[k]] = j;
+      if (takem & (1u << k)) grouped[at[k]] = jb[k];
+      else if (backm & (1u << k)) defer_out[o++] = jb[k];
     }
     __syncthreads();
   }

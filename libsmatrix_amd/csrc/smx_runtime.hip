@@ -58,8 +58,23 @@ namespace {
 
 inline void chunk_pool_trim();
 // hipMalloc that, when the device is out of memory, first gives the pooled chunks of closed matrices back (ChunkPool)
+// (SMATRIX_TRACE_ROUNDS: device allocations and frees of this thread, counted and timed -- a first batch makes dozens)
+struct AllocClock { uint64_t n_alloc = 0, n_free = 0; double s_alloc = 0, s_free = 0; };
+inline AllocClock& alloc_clock() { static thread_local AllocClock c; return c; }
+inline double mono_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+inline bool trace_alloc() { static const bool on = getenv("SMATRIX_TRACE_ALLOC") != nullptr; return on; }
+inline hipError_t dev_free(void* p) {
+  const double t0 = mono_s();
+  const hipError_t e = hipFree(p);
+  AllocClock& c = alloc_clock(); c.n_free++; c.s_free += mono_s() - t0;
+  if (trace_alloc()) fprintf(stderr, "[smatrix]     free %p  %.3f ms\n", p, (mono_s() - t0) * 1e3);
+  return e;
+}
 template <typename T>
 inline void dev_malloc(T** p, size_t bytes) {
+  struct Tick { double t0 = mono_s(); size_t b; ~Tick() { AllocClock& c = alloc_clock(); c.n_alloc++; c.s_alloc += mono_s() - t0;
+                  if (trace_alloc()) fprintf(stderr, "[smatrix]     alloc %zu bytes  %.3f ms\n", b, (mono_s() - t0) * 1e3); } } tick;
+  tick.b = bytes;
   if (hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess) return;
   (void)hipGetLastError();
   chunk_pool_trim();
@@ -240,17 +255,53 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;
+  bool pooled = false;                 // allocated with hipMallocAsync (need_on)
   void need(size_t n) {
     if (n <= cap) return;
-    if (p) HIP_OK(hipFree(p));
+    if (p) HIP_OK(dev_free(p));
     size_t c = std::max<size_t>(n, cap * 2);
     dev_malloc(&p, c * sizeof(T));
     cap = c;
+    pooled = false;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) (void)dev_free(p);          // (hipFree also takes stream-ordered allocations: it waits for the device)
     p = nullptr;
     cap = 0;
+    pooled = false;
+  }
+  // Stream-ordered variants for scratch that lives for one batch and is used on ONE stream (the cold start's key set and
+  // lists): hipFree of >= 64 MB costs 0.21 ms whatever the device is doing (tools/probe/free_cost.cpp) -- seven of them were
+  // 1.5 ms of a 9.6 ms first batch -- while hipFreeAsync hands the memory back to the device's pool in 5 us.
+  void need_on(size_t n, hipStream_t s) {
+    if (n <= cap) return;
+    release_on(s);
+    size_t c = n;
+    const double t0 = mono_s();
+    if (hipMallocAsync(reinterpret_cast<void**>(&p), c * sizeof(T), s) == hipSuccess) {
+      pooled = true;
+      AllocClock& ac = alloc_clock(); ac.n_alloc++; ac.s_alloc += mono_s() - t0;
+      if (trace_alloc()) fprintf(stderr, "[smatrix]     alloc (stream-ordered) %zu bytes  %.3f ms\n", c * sizeof(T), (mono_s() - t0) * 1e3);
+    } else {
+      (void)hipGetLastError();
+      p = nullptr;
+      dev_malloc(&p, c * sizeof(T));
+      pooled = false;
+    }
+    cap = c;
+  }
+  void release_on(hipStream_t s) {
+    if (p && pooled) {
+      const double t0 = mono_s();
+      HIP_OK(hipFreeAsync(p, s));
+      AllocClock& ac = alloc_clock(); ac.n_free++; ac.s_free += mono_s() - t0;
+      if (trace_alloc()) fprintf(stderr, "[smatrix]     free (stream-ordered) %p  %.3f ms\n", (void*)p, (mono_s() - t0) * 1e3);
+    } else if (p) {
+      (void)dev_free(p);
+    }
+    p = nullptr;
+    cap = 0;
+    pooled = false;
   }
 };
 
@@ -556,7 +607,7 @@ struct Matrix {
   uint32_t fix_presize_min = 1u << 18;  // deferred ops from which the rows to create are counted first (SMATRIX_BULK_PRESIZE_MIN; ~0: never)
   uint32_t fix_min = 1u << 14;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN): its fixed cost is ~6 small
                                         // launches and 3 read-backs, about two rounds of the loop it replaces
-  DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped;
+  DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped, fx_rank;
   uint32_t fx_dir_size = 0;             // directory size fx_cnt / fx_cur / fx_pos were laid out (and zeroed) for
   DevBuf<uint64_t> fx_excl, fx_tiles;
   // the speculative chain (run_write): on when the previous write batch was finished by its round 1
@@ -624,12 +675,14 @@ void ensure_free_cap(Matrix* m, uint32_t c, uint64_t extra, hipStream_t s) {
   const uint64_t have = m->free_cnt[c] > 0 ? (uint64_t)m->free_cnt[c] : 0;
   const uint64_t need = have + extra;
   if (need <= m->fl.cap[c]) return;
-  const uint64_t ncap = std::max<uint64_t>(need, (uint64_t)m->fl.cap[c] * 2);
+  // (twice what is asked for: a young table's task counts creep up from batch to batch -- 116 818, 118 736, ... -- and a stack
+  //  sized exactly was reallocated in every one of them, each time with a hipFree that waits for the device: 0.4 ms a batch)
+  const uint64_t ncap = std::max<uint64_t>(2 * need, (uint64_t)m->fl.cap[c] * 2);
   uint32_t* np = nullptr;
   dev_malloc(&np, ncap * sizeof(uint32_t));
   if (have) HIP_OK(hipMemcpyAsync(np, m->fl.list[c], have * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
   HIP_OK(hipStreamSynchronize(s));
-  if (m->fl.list[c]) HIP_OK(hipFree(m->fl.list[c]));
+  if (m->fl.list[c]) HIP_OK(dev_free(m->fl.list[c]));
   m->fl.list[c] = np;
   m->fl.cap[c] = (uint32_t)std::min<uint64_t>(ncap, 0x7fffffffu);
 }
@@ -666,7 +719,7 @@ void grow_directory(Matrix* m, uint32_t factor, hipStream_t s) {
                      m->dir_size, nd, ns - 1);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(s));
-  HIP_OK(hipFree(m->d_dir));
+  HIP_OK(dev_free(m->d_dir));
   m->d_dir = nd;
   m->dir_size = ns;
   m->st.dir_grown++;
@@ -884,7 +937,7 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   if (nd >= m->fix_presize_min && nd / 16 >= m->dir_size) {
     uint64_t slots = 1u << 16;
     while (slots < 2ull * std::min<uint64_t>(nd, 1ull << 27)) slots <<= 1;
-    m->cold_set.need(slots);
+    m->cold_set.need_on(slots, s);                    // (kept: the cold start's key set is the same size; run_write releases it)
     zero_async(m->cold_set.p, slots * 8, s);
     HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 8, s));
     hipLaunchKernelGGL(k_fix_count_rows, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXR_OPT), 4096)), dim3(256), 0, s, m->d_dir, m->dir_size - 1, nd, dl,
@@ -902,7 +955,6 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
       fprintf(stderr, "[smatrix] batch %llu bulk path: %u ops name %u rows the directory lacks; directory %u -> %llu slots\n",
               (unsigned long long)m->st.batches, nd, m->h_small[12] + m->h_small[13], m->dir_size, (unsigned long long)size);
     if (size > m->dir_size) grow_directory(m, (uint32_t)(size / m->dir_size), s);
-    m->cold_set.release();
   }
   for (int tries = 0;; tries++) {
     if (tries > 40) smx_die("bulk path: the directory does not take the batch's rows");
@@ -932,17 +984,17 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   const uint32_t rows_max = (uint32_t)std::min<uint64_t>(nd, m->dir_used);          // touched rows at most
   const uint32_t ntiles = (rows_max + SCAN_TILE - 1) / SCAN_TILE;
   m->fx_touched.need(std::max<uint32_t>(rows_max, 1)); m->fx_excl.need(std::max<uint32_t>(rows_max, 1)); m->fx_tiles.need(ntiles + 2);
-  m->fx_where.need(nd); m->fx_grouped.need(nd);
+  m->fx_where.need(nd); m->fx_grouped.need(nd); m->fx_rank.need(nd);
   ctl_reset_round(m, s);                                       // n_defer: what is handed back; n_tasks: rows touched
   hipLaunchKernelGGL(k_fix_count, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXC_OPT), 8192)), dim3(256), 0, s, m->d_ctl, m->d_dir, ds - 1, nd,
-                     dl, x, y, m->in_stride, m->fx_cnt.p, m->fx_where.p, dl_out, m->fx_touched.p, m->fx_pos.p);
+                     dl, x, y, m->in_stride, m->fx_cnt.p, m->fx_where.p, dl_out, m->fx_touched.p, m->fx_pos.p, m->fx_rank.p);
   HIP_OK(hipMemsetAsync(m->fx_tiles.p + ntiles, 0, 16, s));     // {total, "rows of the wide class exist"}
   hipLaunchKernelGGL(k_fix_scan_tiles, dim3(std::max(ntiles, 1u)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->fx_cnt.p, m->fx_touched.p,
                      m->fx_excl.p, m->fx_tiles.p, m->fx_tiles.p + ntiles + 1);
   hipLaunchKernelGGL(k_fix_scan_tops, dim3(1), dim3(1024), 0, s, m->fx_tiles.p, ntiles, m->fx_tiles.p + ntiles);
   hipLaunchKernelGGL(k_fix_scan_add, dim3(blocks_for(std::max<uint32_t>(rows_max, 1))), dim3(256), 0, s, m->d_ctl, m->fx_excl.p, m->fx_tiles.p);
   hipLaunchKernelGGL(k_fix_scatter, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXC_OPT), 8192)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->fx_cnt.p, nd, dl, m->fx_where.p, m->fx_excl.p,
-                     m->fx_pos.p, m->fx_cur.p, m->fx_grouped.p, dl_out);
+                     m->fx_pos.p, m->fx_rank.p, m->fx_grouped.p, dl_out);
   HIP_OK(hipGetLastError());
   uint64_t tw[2] = {0, 0};
   HIP_OK(hipMemcpyAsync(tw, m->fx_tiles.p + ntiles, 16, hipMemcpyDeviceToHost, s));
@@ -998,8 +1050,8 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   // 1. distinct keys
   uint64_t slots = 1;
   while (slots < 2ull * n_list) slots <<= 1;
-  m->cold_set.need(slots);
-  m->cold_reps.need(n_list);
+  m->cold_set.need_on(slots, s);
+  m->cold_reps.need_on(n_list, s);
   zero_async(m->cold_set.p, slots * 8, s);
   HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 4, s));      // (words 0..9 of the scratch belong to the scalar path and the partition)
   hipLaunchKernelGGL(k_dedup_keys, dim3(std::min<uint32_t>(blocks_for(n_list, DEDUP_THREADS * DEDUP_TRIPS), 4096)), dim3(DEDUP_THREADS), 0, s,
@@ -1010,7 +1062,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   uint32_t cur_n = m->h_small[12];
   if (m->trace_rounds)
     fprintf(stderr, "[smatrix] batch %llu cold start: %u pending ops name %u distinct keys\n", (unsigned long long)m->st.batches, n_list, cur_n);
-  if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) { m->cold_set.release(); m->cold_reps.release(); return false; }
+  if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) return false;      // (the scratch stays while the table is young: run_write)
   m->st.cold_starts++;
   m->st.cold_keys += cur_n;
   // 2. the rounds, over the keys
@@ -1024,7 +1076,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
     m->klist.need(4 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
-    m->cold_defer[round & 1].need(cur_n);
+    m->cold_defer[round & 1].need_on(cur_n, s);
     uint32_t* dl = m->cold_defer[round & 1].p;
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
     ctl_reset_round(m, s);
@@ -1066,9 +1118,8 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     idx = dl;
     cur_n = nd;
   }
-  // (a cold start happens once in a matrix's life: its scratch -- 256 MB for the first batch of config 2 -- goes back)
-  HIP_OK(hipStreamSynchronize(s));
-  m->cold_set.release(); m->cold_reps.release(); m->cold_defer[0].release(); m->cold_defer[1].release();
+  // (its scratch -- 325 MB for the first batch of config 2 -- stays until the table has left its youth: the next batches try the
+  //  same reduction again, and giving 64-256 MB back to the driver costs 0.2 ms a piece; run_write releases it)
   return true;
 }
 
@@ -1130,8 +1181,9 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     ctl_reset_round(m, s);
     // a large write batch into an EMPTY matrix: no row exists, so round 0 of the op kernel would defer every single op
     // (0.45 ms per 2^24 ops to find that out): the deferred list is the batch itself, in order, and the bulk path takes over
+    // (incr / decr only: a set batch's round 0 is k_set_fold, whose entries the passes after the rounds need)
     const bool all_new = round == 0 && !chained && m->dir_used == 0 && m->bulk_enabled && m->expect_bulk && n >= m->fix_min &&
-                         n >= m->agg_min && m->dbg_after == 0;
+                         n >= m->agg_min && m->dbg_after == 0 && (op == OP_INCR || op == OP_DECR);
     if (all_new) {
       hipLaunchKernelGGL(k_iota, dim3(std::min<uint32_t>(blocks_for(n), 4096)), dim3(256), 0, s, dl, n);
       HIP_OK(hipGetLastError());
@@ -1153,9 +1205,9 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       // the previous batch deferred a large share of its ops (bulk load, young matrix): look at this one's count
       // before prep -- one extra read-back, only in this regime -- and group a large remainder by row instead of
       // walking it through a round per doubling
-      ctl_read(m, s);
+      if (!all_new) ctl_read(m, s);                          // (an empty matrix defers the whole batch: nothing to read)
       if (timed0) { account_kernel_time(m, op, n); timed0 = false; }
-      const uint32_t nd0 = m->h_ctl->n_defer;
+      const uint32_t nd0 = all_new ? n : m->h_ctl->n_defer;
       m->expect_bulk = (uint64_t)nd0 * 8 >= n;
       // worth it when a LARGE share of the batch is pending (bulk loads, the first batch of a matrix: every op names a
       // row that does not exist yet).  At 10-15 % -- batches 1 and 2 of config 2 -- grouping costs more than the rounds
@@ -1323,6 +1375,18 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   // the chain is for batches near the steady shape (a few rounds: whatever its rounds 0 and 1 leave is finished by the
   // host-driven loop at no extra cost); young tables with many rounds per batch stay host-driven
   m->spec_ready = rounds_this_batch <= 4;
+  // the cold start's scratch (and the key set the bulk path's row count may have left behind) goes back once a batch has
+  // had the steady shape -- or at once when this batch made no use of it beyond the row count
+  if (m->spec_ready || !cold_tried) {
+    m->cold_set.release_on(s); m->cold_reps.release_on(s); m->cold_defer[0].release_on(s); m->cold_defer[1].release_on(s);
+  }
+  if (m->trace_rounds) {
+    AllocClock& ac = alloc_clock();
+    if (ac.n_alloc + ac.n_free)
+      fprintf(stderr, "[smatrix] batch %llu: %llu device allocations %.3f ms, %llu frees %.3f ms\n", (unsigned long long)m->st.batches,
+              (unsigned long long)ac.n_alloc, ac.s_alloc * 1e3, (unsigned long long)ac.n_free, ac.s_free * 1e3);
+    ac = AllocClock();
+  }
 
   if (op == OP_SET && m->set_entries) {
     // highest-index-wins across tiles, over the winners of k_set_fold only (locate also clears the value word)
@@ -1570,6 +1634,18 @@ smatrix_t* smatrix_open(const char* fname) {
   m->map_old.need((size_t)1 << 20);
   m->map_new.need((size_t)1 << 21);
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, c < 12 ? 1u << 18 : 1u << 12, m->stream);
+  {
+    // the device's stream-ordered pool (DevBuf::need_on: scratch of one batch): freed memory stays in it up to 1 GB instead of
+    // going back to the driver at the next synchronisation, and its first use -- 8 ms to set the pool up -- happens here
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+      uint64_t keep = 1ull << 30;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      void* warm = nullptr;
+      if (hipMallocAsync(&warm, 4096, m->stream) == hipSuccess) (void)hipFreeAsync(warm, m->stream);
+    }
+    (void)hipGetLastError();
+  }
   HIP_OK(hipStreamSynchronize(m->stream));
   ctl_push_persistent(m, m->stream);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2>),
@@ -1641,7 +1717,8 @@ void smatrix_close(smatrix_t* self) {
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
-      m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_excl.release(); m->fx_tiles.release();
+      m->cold_set.release(); m->cold_reps.release(); m->cold_defer[0].release(); m->cold_defer[1].release();
+      m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_rank.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
       get_timing_resolve(m, 0);
@@ -2196,7 +2273,13 @@ int smatrix_reserve(smatrix_t* self, uint64_t bytes) {
 }
 
 // physical chunks kept from closed matrices (ChunkPool) go back to the driver now
-void smatrix_release_cached_memory(void) { chunk_pool().trim(); }
+void smatrix_release_cached_memory(void) {
+  chunk_pool().trim();
+  int dev = 0;
+  hipMemPool_t pool = nullptr;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+  (void)hipGetLastError();
+}
 
 // ---- introspection -------------------------------------------------------------------
 void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
