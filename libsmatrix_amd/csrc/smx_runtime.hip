@@ -278,7 +278,8 @@ struct DevBuf {
     release_on(s);
     size_t c = n;
     const double t0 = mono_s();
-    if (hipMallocAsync(reinterpret_cast<void**>(&p), c * sizeof(T), s) == hipSuccess) {
+    static const bool use_pool = !(getenv("SMATRIX_SCRATCH_POOL") && *getenv("SMATRIX_SCRATCH_POOL") == '0');
+    if (use_pool && hipMallocAsync(reinterpret_cast<void**>(&p), c * sizeof(T), s) == hipSuccess) {
       pooled = true;
       AllocClock& ac = alloc_clock(); ac.n_alloc++; ac.s_alloc += mono_s() - t0;
       if (trace_alloc()) fprintf(stderr, "[smatrix]     alloc (stream-ordered) %zu bytes  %.3f ms\n", c * sizeof(T), (mono_s() - t0) * 1e3);
