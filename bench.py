@@ -1025,15 +1025,24 @@ def main():
     if sharded and args.c_router:
         from libsmatrix_amd.sharded import NativeShardedMatrix
         m, why = None, None
+
+        def any_rank_failed(reason):
+            # every rank must take the same router: agree on the worst outcome (one small all-reduce)
+            flag = torch.tensor([0 if reason is None else 1], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            return bool(int(flag.item()))
         try:
-            m = NativeShardedMatrix()
-            preflight_router(torch, dev, m, stream)
+            m = NativeShardedMatrix()                           # (RCCL loaded, the id travelled, ncclCommInitRank done)
         except Exception as e:                                  # noqa: BLE001
             why = "%s: %s" % (type(e).__name__, e)
-        # every rank must take the same router: agree on the worst outcome
-        flag = torch.tensor([0 if why is None else 1], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()):
+        failed = any_rank_failed(why)                           # BEFORE the first collective of the router: a rank without a handle cannot take part in it
+        if not failed:
+            try:
+                preflight_router(torch, dev, m, stream)
+            except Exception as e:                              # noqa: BLE001
+                why = "%s: %s" % (type(e).__name__, e)
+            failed = any_rank_failed(why)
+        if failed:
             # the library's own RCCL path is not usable here (RCCL missing, communicator refused): say so once and take the
             # torch.distributed router -- same partition kernels, same shards, the exchange issued by torch
             print("bench.py rank %d: C router unavailable (%s) -- falling back to the torch.distributed router" % (rank, why or "a peer failed"),

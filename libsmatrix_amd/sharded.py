@@ -592,11 +592,12 @@ class NativeShardedMatrix:
             box = [None]
             if rank == 0:
                 buf = C.create_string_buffer(128)
-                if self._lib.smatrix_shard_unique_id(buf):
-                    raise RuntimeError("RCCL is not available (smatrix_shard_unique_id)")
-                box[0] = bytes(buf.raw)
-            dist.broadcast_object_list(box, src=0)
+                if self._lib.smatrix_shard_unique_id(buf) == 0:
+                    box[0] = bytes(buf.raw)
+            dist.broadcast_object_list(box, src=0)               # (None when rank 0 has no RCCL: the others must not wait for an id that never comes)
             unique_id = box[0]
+            if unique_id is None:
+                raise RuntimeError("RCCL is not available on rank 0 (smatrix_shard_unique_id)")
         idbuf = C.create_string_buffer(unique_id, 128) if unique_id else None
         self._h = self._lib.smatrix_shard_open(filename.encode() if filename else None, rank, world, idbuf)
         if not self._h:
