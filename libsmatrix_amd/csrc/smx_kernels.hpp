@@ -550,9 +550,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS
 // of what was refused) per row and workgroup; a lane with a ticket keeps it until its key is in (nobody else inserts
 // that key).  Big rows (sub-counter quotas) and long probe sequences take the general path.
 constexpr uint32_t INS_THREADS = 1024;
+// Round 4: the keys travel PACKED -- n 64-bit keys (x << 32 | y) in `kin`, the ones that stay deferred written to `kout` the same
+// way (one reservation per workgroup, as before).  A round used to read an index list and gather x and y of every listed op from
+// the batch's arrays (two random 4-byte loads per key and round out of 134 MB, again in k_prep); now every round streams its input.
 __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
-    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
-    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t* defer, uint32_t st) {
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const unsigned long long* __restrict__ kin,
+    unsigned long long* __restrict__ kout) {
   __shared__ uint32_t l_row[2 * INS_THREADS], l_cnt[2 * INS_THREADS], l_grant[2 * INS_THREADS];
   __shared__ uint32_t l_n, l_base;
   for (uint64_t t064 = (uint64_t)blockIdx.x * INS_THREADS; t064 < n; t064 += (uint64_t)gridDim.x * INS_THREADS) {   // block-uniform
@@ -560,16 +563,17 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     const bool live = t < n;
     for (uint32_t i = threadIdx.x; i < 2 * INS_THREADS; i += INS_THREADS) { l_row[i] = 0xFFFFFFFFu; l_cnt[i] = 0; }
     if (threadIdx.x == 0) l_n = 0;
-    uint32_t j = 0, Y = 0, pos = 0, mask = 0, e = 0, rank = 0;
+    unsigned long long key = 0;
+    uint32_t Y = 0, pos = 0, mask = 0, e = 0, rank = 0;
     bool deferred = false, need = false, general = false;
     uint4 s = {0, 0, 0, 0};
     DirSlot* d = nullptr;
     uint64_t* cells = nullptr;
     LongProbe lp{false, nullptr, 0, 0};
     if (live) {
-      j = idx[t];
-      Y = ys[(size_t)j * st];
-      d = dir_find(dir, dmask, xs[(size_t)j * st], &s);
+      key = kin[t];
+      Y = (uint32_t)key;
+      d = dir_find(dir, dmask, (uint32_t)(key >> 32), &s);
       if (!d || s.z == 0) deferred = true;                       // the row does not exist (yet): prep creates it
       else if (Y == 0) general = true;
       else if (meta_lg(s.x) < BIG_LG ? s.w > (1u << meta_lg(s.x)) / 2u
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     __syncthreads();
     if (threadIdx.x == 0 && l_n) l_base = atomicAdd(&ctl->n_defer, l_n);
     __syncthreads();
-    if (deferred) defer[l_base + wbase + (uint32_t)__popcll(dm & ((1ull << __lane_id()) - 1ull))] = j;
+    if (deferred) kout[l_base + wbase + (uint32_t)__popcll(dm & ((1ull << __lane_id()) - 1ull))] = key;
     __syncthreads();                                             // the LDS tables are reused by the next trip
   }
 }
@@ -671,8 +675,8 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
 constexpr uint32_t DEDUP_THREADS = 1024, DEDUP_TRIPS = 8;
 __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs,
                                                              const uint32_t* __restrict__ ys, uint32_t st, unsigned long long* set,
-                                                             uint64_t set_mask, uint32_t* reps, uint32_t* n_reps) {
-  __shared__ uint32_t l_rep[DEDUP_THREADS * DEDUP_TRIPS];
+                                                             uint64_t set_mask, unsigned long long* reps, uint32_t* n_reps) {
+  __shared__ unsigned long long l_rep[DEDUP_THREADS * DEDUP_TRIPS];     // (round 4: the distinct keys themselves, x << 32 | y)
   __shared__ uint32_t l_n, l_base;
   for (uint64_t b0 = (uint64_t)blockIdx.x * DEDUP_THREADS * DEDUP_TRIPS; b0 < n; b0 += (uint64_t)gridDim.x * DEDUP_THREADS * DEDUP_TRIPS) {
     if (threadIdx.x == 0) l_n = 0;
@@ -680,12 +684,12 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
     for (uint32_t k = 0; k < DEDUP_TRIPS; k++) {
       const uint64_t t = b0 + (uint64_t)k * DEDUP_THREADS + threadIdx.x;
       bool won = false;
-      uint32_t j = 0;
+      unsigned long long key = 0;
       if (t < n) {
-        j = idx[t];
+        const uint32_t j = idx[t];
         const uint32_t X = xs[(size_t)j * st], Y = ys[(size_t)j * st];
         if (Y != 0) {                                     // (y == 0 never inserts: quirk Q1)
-          const unsigned long long key = ((unsigned long long)X << 32) | Y;
+          key = ((unsigned long long)X << 32) | Y;
           uint64_t h = splitmix_at(0x5eedull, key) & set_mask;
           for (;;) {
             // (a plain look first: a hot key has 10^5 duplicates, and as many CAS on its slot queue at the memory side --
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
       uint32_t wb = 0;
       if (wm && __lane_id() == 0) wb = atomicAdd(&l_n, (uint32_t)__popcll(wm));
       wb = __shfl(wb, 0);
-      if (won) l_rep[wb + (uint32_t)__popcll(wm & ((1ull << __lane_id()) - 1ull))] = j;
+      if (won) l_rep[wb + (uint32_t)__popcll(wm & ((1ull << __lane_id()) - 1ull))] = key;
     }
     __syncthreads();
     if (threadIdx.x == 0 && l_n) l_base = atomicAdd(n_reps, l_n);
@@ -1081,7 +1085,7 @@ __device__ __forceinline__ void prep_body(
     const bool live = t < n;
     uint32_t X = 0, Y = 0;
     if (live) {
-      const uint32_t j = defer[t];
+      const uint32_t j = defer ? defer[t] : t;         // (no list: the ops are the n_defer entries of xs / ys themselves -- packed keys)
       X = xs[(size_t)j * st];
       Y = ys[(size_t)j * st];
     }
@@ -1489,6 +1493,55 @@ __global__ __launch_bounds__(256) void k_fix_count_rows(const DirSlot* dir, uint
     if (threadIdx.x == 0 && l_won) atomicAdd(n_missing, l_won);
     if (threadIdx.x == 0 && l_none) n_missing[1] = 1;               // (benign race: all store 1)
     __syncthreads();
+  }
+}
+
+// pass 0b (round 4): the rows pass 0a has just counted, created FROM ITS SET -- every non-empty slot of the scratch set is one
+// distinct missing row id (id + 1), so creation is a sweep over the set's slots (268 MB for a 2^24-op batch, ~0.7 M rows)
+// instead of a second fold of all 16.7 M ops (k_fix_create: 0.41 ms).  The directory was sized for them by the host, nobody
+// else creates rows meanwhile, ids are distinct: a compare-and-swap on the first empty slot of the probe sequence always
+// wins in the end.  Reservations (directory count, retired 16-cell blocks, arena units) once per workgroup, as in pass 0.
+constexpr uint32_t FIXS_OPT = 16;
+__global__ __launch_bounds__(256) void k_fix_create_set(Ctl* ctl, DirSlot* dir, uint32_t dmask, const unsigned long long* __restrict__ set,
+                                                        uint64_t set_slots, uint64_t arena_cap_units, FreeLists fl) {
+  // a workgroup owns one contiguous range of the set: it counts the range's rows first, reserves ONCE (three words that
+  // every workgroup needs: one reservation per 4096 slots queued 8 192 x 3 same-address atomics, 1 ms), then creates
+  __shared__ uint32_t l_total, l_next, l_got, l_top;
+  __shared__ unsigned long long l_u0;
+  const uint64_t chunk = ((set_slots + gridDim.x - 1) / gridDim.x + 255u) & ~255ull;
+  const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(lo + chunk, set_slots);
+  if (threadIdx.x == 0) { l_total = 0; l_next = 0; }
+  __syncthreads();
+  uint32_t cnt = 0;
+  for (uint64_t t = lo + threadIdx.x; t < hi; t += 256) cnt += set[t] != 0ull;
+  if (cnt) atomicAdd(&l_total, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0 && l_total) {
+    const uint32_t n_new = l_total;
+    atomicAdd(&ctl->dir_used, n_new);                                // (the host sized the directory for exactly these rows)
+    const int32_t top = atomicSub(&ctl->free_cnt[0], (int32_t)n_new);            // retired (zeroed) 16-cell blocks first
+    const uint32_t got = top > 0 ? min((uint32_t)top, n_new) : 0u;
+    if (got < n_new) atomicAdd(&ctl->free_cnt[0], (int32_t)(n_new - got));
+    if (got < n_new) l_u0 = atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->arena_next), (unsigned long long)(n_new - got));
+    l_got = got;
+    l_top = (uint32_t)top;
+  }
+  __syncthreads();
+  if (l_total == 0) return;
+  for (uint64_t t = lo + threadIdx.x; t < hi; t += 256) {
+    const unsigned long long key = set[t];
+    if (!key) continue;
+    const uint32_t X = (uint32_t)(key - 1ull), rank = atomicAdd(&l_next, 1u);
+    const uint64_t want = (uint64_t)(META_USED | META_DIRTY | (ROW_FIRST_LG << META_LG_SHIFT)) | ((uint64_t)X << 32);
+    uint32_t h = fmix32(X) & dmask;
+    for (;;) {
+      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&dir[h]), 0ull, (unsigned long long)want);
+      if (prev == 0) break;
+      h = (h + 1) & dmask;                                           // (another new row took it: ids are distinct, walk on)
+    }
+    const uint64_t u = rank < l_got ? fl.list[0][l_top - 1u - rank] : l_u0 + (rank - l_got);
+    if (u >= arena_cap_units) ctl->arena_oom = 1;                   // the host guarantees this never fires
+    else __hip_atomic_store(&dir[h].base, (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

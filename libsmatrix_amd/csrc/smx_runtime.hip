@@ -631,7 +631,7 @@ struct Matrix {
                                         // first chunk of the CF import has 3 M of 2^25 ops pending when its rows have been created, and needs it:
                                         // 0.036 against 0.126 s.  The price is 0.12 ms of de-duplication that finds nothing in batch 2 of config 2.)
   DevBuf<unsigned long long> cold_set;
-  DevBuf<uint32_t> cold_reps, cold_defer[2];
+  DevBuf<unsigned long long> cold_keys[2];   // the distinct pending keys, packed; what a round leaves deferred
 };
 
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
@@ -935,6 +935,7 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   // (k_fix_count_rows), instead of running the creation pass into "directory full" once per factor of four
   // (only when the list dwarfs the directory -- the first batches of a matrix; a bulk load in progress, whose directory has
   //  grown with its rows, keeps the cheap path: one creation pass, now and then a rebuild)
+  bool created_from_set = false;
   if (nd >= m->fix_presize_min && nd / 16 >= m->dir_size) {
     uint64_t slots = 1u << 16;
     while (slots < 2ull * std::min<uint64_t>(nd, 1ull << 27)) slots <<= 1;
@@ -956,8 +957,26 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
       fprintf(stderr, "[smatrix] batch %llu bulk path: %u ops name %u rows the directory lacks; directory %u -> %llu slots\n",
               (unsigned long long)m->st.batches, nd, m->h_small[12] + m->h_small[13], m->dir_size, (unsigned long long)size);
     if (size > m->dir_size) grow_directory(m, (uint32_t)(size / m->dir_size), s);
+    // ... and the rows are created from the set itself (k_fix_create_set): a sweep over its slots instead of a second fold of
+    // the whole list.  The creation pass below then finds every row in place -- it is kept for the one id the set cannot
+    // hold (0xFFFFFFFF) and runs only when that id was seen.
+    if (need > m->dir_used && need <= m->dir_size / 2) {
+      ensure_arena_free(m, need - m->dir_used, s);
+      hipLaunchKernelGGL(k_fix_create_set, dim3((uint32_t)std::min<uint64_t>(blocks_for(slots, 256 * FIXS_OPT), 1024)), dim3(256), 0, s, m->d_ctl, m->d_dir,
+                         m->dir_size - 1, m->cold_set.p, slots, (uint64_t)(m->arena.mapped / UNIT_BYTES), m->fl);
+      HIP_OK(hipGetLastError());
+      created_from_set = true;                               // (k_fix_create leaves the id 0xFFFFFFFF to the round loop's prep as well)
+      // the grouping passes' buffers, allocated while the sweep runs
+      m->fx_where.need(nd); m->fx_grouped.need(nd); m->fx_rank.need(nd);
+      const uint32_t rows_guess = (uint32_t)std::min<uint64_t>(nd, need);
+      m->fx_touched.need(std::max<uint32_t>(rows_guess, 1)); m->fx_excl.need(std::max<uint32_t>(rows_guess, 1));
+      m->fx_tiles.need((rows_guess + SCAN_TILE - 1) / SCAN_TILE + 2);
+      if (m->fx_dir_size != m->dir_size) { m->fx_cnt.need(m->dir_size); m->fx_cur.need(m->dir_size); m->fx_pos.need(m->dir_size); }
+      ctl_read(m, s);
+      if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
+    }
   }
-  for (int tries = 0;; tries++) {
+  for (int tries = 0; !created_from_set; tries++) {
     if (tries > 40) smx_die("bulk path: the directory does not take the batch's rows");
     const uint32_t dir_limit = m->dir_size / 2;
     const uint32_t room = dir_limit > m->dir_used ? dir_limit - m->dir_used : 0;
@@ -966,6 +985,15 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
     hipLaunchKernelGGL(k_fix_create, dim3(std::min<uint32_t>(blocks_for(nd, 256 * FIXR_OPT), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir,
                        m->dir_size - 1, dir_limit, nd, dl, x, m->in_stride, (uint64_t)(m->arena.mapped / UNIT_BYTES), m->fl);
     HIP_OK(hipGetLastError());
+    if (tries == 0) {
+      // (round 4) the grouping passes' buffers are allocated WHILE the creation pass runs -- a dozen hipMallocs, 0.15 ms of an
+      // idle GPU when they came behind the read-back (they are sized for the op count, or grow again with the directory)
+      m->fx_where.need(nd); m->fx_grouped.need(nd); m->fx_rank.need(nd);
+      const uint32_t rows_guess = (uint32_t)std::min<uint64_t>(nd, (uint64_t)m->dir_size / 2);
+      m->fx_touched.need(std::max<uint32_t>(rows_guess, 1)); m->fx_excl.need(std::max<uint32_t>(rows_guess, 1));
+      m->fx_tiles.need((rows_guess + SCAN_TILE - 1) / SCAN_TILE + 2);
+      if (m->fx_dir_size != m->dir_size) { m->fx_cnt.need(m->dir_size); m->fx_cur.need(m->dir_size); m->fx_pos.need(m->dir_size); }
+    }
     ctl_read(m, s);
     if (m->h_ctl->arena_oom) smx_die("internal: arena reservation too small");
     const bool full = m->h_ctl->dir_full != 0;
@@ -984,6 +1012,9 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   }
   const uint32_t rows_max = (uint32_t)std::min<uint64_t>(nd, m->dir_used);          // touched rows at most
   const uint32_t ntiles = (rows_max + SCAN_TILE - 1) / SCAN_TILE;
+  // (the stacks of retired blocks get their room NOW, while the stream is idle: a stack that has to grow copies its
+  //  contents and waits for the stream -- between the scatter pass and the row pass that was 0.1 ms of idle GPU)
+  for (uint32_t c = 0; c <= FIX_MAX_LG - ROW_FIRST_LG; c++) ensure_free_cap(m, c, rows_max, s);
   m->fx_touched.need(std::max<uint32_t>(rows_max, 1)); m->fx_excl.need(std::max<uint32_t>(rows_max, 1)); m->fx_tiles.need(ntiles + 2);
   m->fx_where.need(nd); m->fx_grouped.need(nd); m->fx_rank.need(nd);
   ctl_reset_round(m, s);                                       // n_defer: what is handed back; n_tasks: rows touched
@@ -1005,8 +1036,6 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   ensure_arena_free(m, units, s);
   if (m->arena_next + units >= (1ull << 32)) smx_die("row arena exhausted");
   const uint64_t new_base0 = m->arena_next;
-  const uint64_t rows_bound = std::min<uint64_t>(nd, m->dir_used);
-  for (uint32_t c = 0; c <= FIX_MAX_LG - ROW_FIRST_LG; c++) ensure_free_cap(m, c, rows_bound, s);
   const dim3 fgrid(std::max<uint32_t>(1, std::min<uint32_t>((rows_max + FIX_WAVES - 1) / FIX_WAVES, 8192)));   // (no row at all: the one id this path leaves to prep)
   hipLaunchKernelGGL((k_fix_rows<OP, FIX_MAX_LG - 1>), fgrid, dim3(64 * FIX_WAVES), 0, s,
                      m->d_ctl, m->d_dir, m->fx_touched.p, m->arena.base, m->fx_cnt.p, m->fx_cur.p, m->fx_excl.p, m->fx_grouped.p, y, v,
@@ -1018,6 +1047,18 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   HIP_OK(hipGetLastError());
   const uint64_t next = new_base0 + units;
   HIP_OK(hipMemcpyAsync(&m->d_ctl->arena_next, &next, 8, hipMemcpyHostToDevice, s));
+  {
+    // (round 4) what the round loop and a cold start will ask for next, allocated while the row passes run: task lists for
+    // the handed-back ops, the packed-key buffer of the distinct pending keys
+    const uint64_t bound = std::min<uint64_t>(nd, m->dir_size);
+    m->tasks.need(bound); m->klist.need(4 * bound); m->rebal.need(bound);
+    if (m->cold_min && nd >= m->cold_min) {
+      uint64_t slots = 1;
+      while (slots < 2ull * nd) slots <<= 1;
+      m->cold_set.need_on(slots, s);
+      m->cold_keys[0].need_on(nd, s);
+    }
+  }
   ctl_read(m, s);
   m->st.bulk_rounds++;
   m->st.bulk_ops += nd - m->h_ctl->n_defer;
@@ -1052,11 +1093,11 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   uint64_t slots = 1;
   while (slots < 2ull * n_list) slots <<= 1;
   m->cold_set.need_on(slots, s);
-  m->cold_reps.need_on(n_list, s);
+  m->cold_keys[0].need_on(n_list, s);
   zero_async(m->cold_set.p, slots * 8, s);
   HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 4, s));      // (words 0..9 of the scratch belong to the scalar path and the partition)
   hipLaunchKernelGGL(k_dedup_keys, dim3(std::min<uint32_t>(blocks_for(n_list, DEDUP_THREADS * DEDUP_TRIPS), 4096)), dim3(DEDUP_THREADS), 0, s,
-                     n_list, list, x, y, m->in_stride, m->cold_set.p, slots - 1, m->cold_reps.p, m->d_small + 12);
+                     n_list, list, x, y, m->in_stride, m->cold_set.p, slots - 1, m->cold_keys[0].p, m->d_small + 12);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
@@ -1066,8 +1107,8 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) return false;      // (the scratch stays while the table is young: run_write)
   m->st.cold_starts++;
   m->st.cold_keys += cur_n;
-  // 2. the rounds, over the keys
-  const uint32_t* idx = m->cold_reps.p;
+  // 2. the rounds, over the keys (packed, x << 32 | y: every round streams its input and writes what stays deferred the same way)
+  const unsigned long long* kin = m->cold_keys[0].p;
   uint32_t stalled = 0, rows_before = m->dir_used;
   for (uint32_t round = 0; cur_n; round++) {
     if (stalled > 8) smx_die("write batch did not converge (corrupt row table?)");
@@ -1077,16 +1118,17 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     m->klist_cap = (uint32_t)std::min<uint64_t>(cur_n, m->dir_size);
     m->klist.need(4 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
-    m->cold_defer[round & 1].need_on(cur_n, s);
-    uint32_t* dl = m->cold_defer[round & 1].p;
+    // (two buffers take turns: the dedup's output, sized for the whole list, and one for the first round's survivors)
+    unsigned long long* kout = (round & 1) ? m->cold_keys[0].p : (m->cold_keys[1].need_on(cur_n, s), m->cold_keys[1].p);
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
     ctl_reset_round(m, s);
     hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base,
-                       cur_n, idx, x, y, dl, m->in_stride);
+                       cur_n, kin, kout);
+    // prep over the survivors: no list, x and y are the high and the low word of the packed keys
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
-                       (uint64_t)(m->arena.mapped / UNIT_BYTES), dl, x, y, m->tasks.p, m->klist.p, m->klist_cap,
-                       m->rebal.p, m->fl, m->in_stride, 2u);
+                       (uint64_t)(m->arena.mapped / UNIT_BYTES), (const uint32_t*)nullptr, reinterpret_cast<const uint32_t*>(kout) + 1,
+                       reinterpret_cast<const uint32_t*>(kout), m->tasks.p, m->klist.p, m->klist_cap, m->rebal.p, m->fl, 2u, 2u);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     m->st.rounds++;
@@ -1116,7 +1158,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     }
     if (c.dir_full) grow_directory(m, 4, s);
     else if ((uint64_t)m->dir_used * 2 >= m->dir_size) grow_directory(m, 2, s);
-    idx = dl;
+    kin = kout;
     cur_n = nd;
   }
   // (its scratch -- 325 MB for the first batch of config 2 -- stays until the table has left its youth: the next batches try the
@@ -1379,7 +1421,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   // the cold start's scratch (and the key set the bulk path's row count may have left behind) goes back once a batch has
   // had the steady shape -- or at once when this batch made no use of it beyond the row count
   if (m->spec_ready || !cold_tried) {
-    m->cold_set.release_on(s); m->cold_reps.release_on(s); m->cold_defer[0].release_on(s); m->cold_defer[1].release_on(s);
+    m->cold_set.release_on(s); m->cold_keys[0].release_on(s); m->cold_keys[1].release_on(s);
   }
   if (m->trace_rounds) {
     AllocClock& ac = alloc_clock();
@@ -1718,7 +1760,7 @@ void smatrix_close(smatrix_t* self) {
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
-      m->cold_set.release(); m->cold_reps.release(); m->cold_defer[0].release(); m->cold_defer[1].release();
+      m->cold_set.release(); m->cold_keys[0].release(); m->cold_keys[1].release();
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_rank.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
