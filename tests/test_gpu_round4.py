@@ -316,3 +316,41 @@ def test_many_rows_flushed_in_steps_stay_fast(G, oracle_mod, monkeypatch, tmp_pa
     pick = np.random.default_rng(3).integers(0, rows, 50000)
     assert (o.apply(0, x[pick], y[pick]) == v[pick]).all()
     o.close()
+
+
+def test_first_batch_rows_created_from_the_count_passes_set(G, oracle_mod):
+    """Round 4: a first batch that dwarfs the directory (>= 16 ops per directory slot) has its missing rows counted exactly
+    (k_fix_count_rows), the directory sized once, and the rows created from the count pass's scratch set (k_fix_create_set)
+    instead of a second fold over all ops.  1.3 M ops naming 320 000 rows -- row ids 0 and 0xFFFFFFFF among them (the set
+    stores id + 1; 0xFFFFFFFF is left to the round loop), hot rows that outgrow the bulk path (they give it their first 2048
+    ops), y == 0 ops -- against the oracle: every row, every rowlen, every cell; then a second batch with new rows on the
+    grown directory."""
+    rng = np.random.default_rng(4242)
+    n = 1300000
+    ids = rng.integers(0, 1 << 32, 320000, dtype=np.uint64).astype(np.uint32)
+    ids[0], ids[1] = 0, 0xFFFFFFFF
+    x = ids[rng.integers(0, ids.size, n)]
+    hot = rng.random(n) < 0.25
+    x[hot] = ids[rng.integers(2, 12, int(hot.sum()))]                     # ten hot rows: ~32 000 ops each
+    y = rng.integers(0, 1 << 20, n, dtype=np.uint32)                       # y == 0 now and then (quirk Q1 path)
+    v = np.ones(n, np.uint32)                                              # (equal increments: per-key return multisets are order-free)
+    g, o = G(), oracle_mod.Oracle()
+    a, b = g.apply(2, x, y, v), o.apply(2, x, y, v)
+    st = g.stats()
+    assert st["rows"] == o.num_rows() and st["bulk_rounds"] >= 1, st
+    assert st["dir_grown"] == 1, st                                         # sized ONCE (65 536 -> its final size)
+    rows = o.list_rows()
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], np.uint32)).all()
+    nz = y != 0
+    assert (g.apply(0, x[nz], y[nz]) == o.apply(0, x[nz], y[nz])).all()
+    for r in (0, 0xFFFFFFFF, int(ids[2]), int(ids[5])):
+        assert g.row_info(r) == o.row_info(r), r
+    # per-key multisets of the returned values (a batch is one legal order)
+    k = x.astype(np.uint64) << 32 | y
+    oa, ob = np.lexsort((a, k)), np.lexsort((b, k))
+    assert (a[oa][nz[oa]] == b[ob][nz[ob]]).all()
+    x2 = rng.integers(0, 1 << 32, 200000, dtype=np.uint64).astype(np.uint32); y2 = rng.integers(1, 1 << 20, 200000, dtype=np.uint32)
+    g.apply(2, x2, y2, np.ones(200000, np.uint32)); o.apply(2, x2, y2, np.ones(200000, np.uint32))
+    assert g.stats()["rows"] == o.num_rows()
+    assert (g.apply(0, x2, y2) == o.apply(0, x2, y2)).all()
+    g.close(); o.close()
