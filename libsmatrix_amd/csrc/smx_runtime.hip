@@ -609,6 +609,7 @@ struct Matrix {
   uint32_t fix_min = 1u << 14;          // deferred ops from which the grouping pays (SMATRIX_BULK_MIN): its fixed cost is ~6 small
                                         // launches and 3 read-backs, about two rounds of the loop it replaces
   DevBuf<uint32_t> fx_cnt, fx_cur, fx_pos, fx_touched, fx_where, fx_grouped, fx_rank;
+  std::vector<void*> put_aside;         // device blocks replaced while kernels were running: freed at the end of the write batch
   uint32_t fx_dir_size = 0;             // directory size fx_cnt / fx_cur / fx_pos were laid out (and zeroed) for
   DevBuf<uint64_t> fx_excl, fx_tiles;
   // the speculative chain (run_write): on when the previous write batch was finished by its round 1
@@ -1047,19 +1048,30 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   HIP_OK(hipGetLastError());
   const uint64_t next = new_base0 + units;
   HIP_OK(hipMemcpyAsync(&m->d_ctl->arena_next, &next, 8, hipMemcpyHostToDevice, s));
+  std::vector<void*> put_aside;
   {
     // (round 4) what the round loop and a cold start will ask for next, allocated while the row passes run: task lists for
     // the handed-back ops, the packed-key buffer of the distinct pending keys
+    // (a buffer that has to grow must not hipFree its old block here -- hipFree waits for the row passes: the old blocks are
+    //  put aside and freed behind the read-back)
     const uint64_t bound = std::min<uint64_t>(nd, m->dir_size);
-    m->tasks.need(bound); m->klist.need(4 * bound); m->rebal.need(bound);
+    const auto grow = [&](auto& buf, size_t n) {
+      if (n <= buf.cap) return;
+      if (buf.p) put_aside.push_back(buf.p);
+      buf.p = nullptr; buf.cap = 0;
+      buf.need(n);
+    };
+    grow(m->tasks, bound); grow(m->klist, 4 * bound); grow(m->rebal, bound);
     if (m->cold_min && nd >= m->cold_min) {
       uint64_t slots = 1;
       while (slots < 2ull * nd) slots <<= 1;
       m->cold_set.need_on(slots, s);
       m->cold_keys[0].need_on(nd, s);
+      m->cold_keys[1].need_on(nd / 4, s);               // (what the first round leaves: usually a quarter of the list names distinct keys)
     }
   }
   ctl_read(m, s);
+  m->put_aside.insert(m->put_aside.end(), put_aside.begin(), put_aside.end());      // (freed at the end of the batch)
   m->st.bulk_rounds++;
   m->st.bulk_ops += nd - m->h_ctl->n_defer;
   return m->h_ctl->n_defer;
@@ -1418,6 +1430,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   // the chain is for batches near the steady shape (a few rounds: whatever its rounds 0 and 1 leave is finished by the
   // host-driven loop at no extra cost); young tables with many rounds per batch stay host-driven
   m->spec_ready = rounds_this_batch <= 4;
+  for (void* q : m->put_aside) (void)dev_free(q);
+  m->put_aside.clear();
   // the cold start's scratch (and the key set the bulk path's row count may have left behind) goes back once a batch has
   // had the steady shape -- or at once when this batch made no use of it beyond the row count
   if (m->spec_ready || !cold_tried) {

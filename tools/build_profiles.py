@@ -168,7 +168,7 @@ lines_f = [
  "  8 waves per SIMD (two 1024-lane workgroups per CU): there is no third workgroup to win, whatever the table costs.  Dropped.",
  "  Round >= 1 in one launch (2a): the growth round's critical path above is kernel time, ~%.2f ms; grouping the ~230 000 deferred ops by row" % (crit / 1e3),
  "  (count, scan, scatter, rows) is five launches of its own -- round 2 measured that fixed cost at what the round costs today.  The bulk",
- "  path was widened where it pays instead: hot rows now give it their first 2048 ops (first incr batch of config 2: 13.0 -> 8.8 ms).",
+ "  path was widened where it pays instead: hot rows now give it their first 2048 ops (first incr batch of config 2: 13.0 -> 8.0 ms).",
 ]
 open(os.path.join(P, RND + "_floor.txt"), "w").write("\n".join(lines_f) + "\n")
 print("\n".join(lines_f))
