@@ -162,7 +162,7 @@ lines_f = [
  "  on one GPU (a 1024-way key split + the un-permuting of results).",
  "  Ticket-free inserts (VERDICT r3 2b): 90.0 % of the inserts land in rows whose room covers the row's TRUE number of new keys, 73.5 % in rows",
  "  whose room covers the row's OP COUNT in the batch -- the only bound a kernel could hold, and computing it (a per-batch row histogram)",
- "  costs one atomic per (tile, row) pair, ~10 M per batch against the 3.7 M tickets it would save.  Estimates from the previous batch cover",
+ "  costs one atomic per (tile, row) pair, 7.98 M per batch (same census) against the 3.7 M tickets it would save.  Estimates from the previous batch cover",
  "  39-70 % but are not bounds: one row that overshoots its threshold breaks the reference's growth rule (src/smatrix.c:343-360).  Dropped.",
  "  Hot/cold split (2c): the whole LDS fold costs 0.14 ms of the kernel (profiles/r02_agg_kernel_phase_shares.txt) and the kernel already runs",
  "  8 waves per SIMD (two 1024-lane workgroups per CU): there is no third workgroup to win, whatever the table costs.  Dropped.",

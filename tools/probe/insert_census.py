@@ -67,6 +67,9 @@ for f in (2, 4, 8):
 for s in (8, 10, 12, 15):
     m = lg >= s
     share(m, 'rows of >= 2^%d cells' % s)
+tile_all = (np.arange(B, dtype=np.uint64) // np.uint64(2048))
+print('    a per-batch row histogram (the bound of the second line) costs one atomic per distinct (tile, row) pair: %d' %
+      np.unique(tile_all << np.uint64(32) | x.astype(np.uint64)).size)
 grow = new_per_row > room
 print('(a) rows that must double in this batch: %d; their inserts %d; ops deferred at least once ~ inserts beyond room: %d' %
       (int(grow.sum()), int(new_per_row[grow].sum()), int((new_per_row[grow] - room[grow]).sum())))
