@@ -280,6 +280,44 @@ __device__ inline uint32_t sub_tickets_bulk(SubCtr* subs, uint32_t k0, uint32_t 
 // hands the probe to its WAVE: 64 lanes look at 64 consecutive cells per load (one coalesced 512-byte window, four
 // windows in flight), two ballots find the first cell that ends the reference's probe -- key == Y or empty
 // (src/smatrix.c:369-377) -- in probe order.
+// Round 4: WHERE a far-from-home key sits is remembered.  Nearly all of a dense batch's long probes are HITS on keys that sat
+// thousands of cells from home the batch before as well (770 000 of 2^24 ops, ~15 000 cells each: 7 ms of wave-per-op passes
+// per step).  A direct-mapped table of {y, row base, slot} entries (the matrix allocates it when its tables turn out clustered)
+// is consulted when a probe has used up its budget, and written when a wave-cooperative probe has ended on the key.  An entry
+// is a HINT: it counts only if the cell it names holds y in the row's CURRENT block (a doubled row has a new base; a torn or
+// overwritten entry fails the same test), and a key sits in one cell of its table -- with one exception, the twins of quirk
+// Q1: a (0, v) cell whose value returns to 0 becomes an empty cell, a key behind it can then be inserted a second time in
+// front, and the reference's probe from home finds THAT one.  So the first write op that leaves a (0, 0) cell behind switches
+// the hints off for the matrix (`y0_zeroed`, sticky): they are an accelerator for dense-id streams, not a structure.
+// Unit 0 of the arena (base 0 = "no block") holds the words the kernels need for this, so that no kernel signature grows.
+struct ArenaHead {
+  uint32_t y0_zeroed;     // a y == 0 write has left a (0, 0) cell (see above)
+  uint32_t hint_mask;     // entries - 1 of the hint table; 0: none
+  uint4* hints;
+};
+static_assert(sizeof(ArenaHead) <= 128, "unit 0 of the arena");
+constexpr uint32_t HINT_BUDGET = 8;        // cells a lane probes before it asks for a hint, when the matrix has a hint table
+__device__ inline uint32_t hint_index(uint32_t base, uint32_t Y, uint32_t hmask) {
+  return fmix32(base * 0x9E3779B1u ^ Y * 0x85EBCA77u) & hmask;
+}
+// the slot of key Y in the table at `cells` (block `base`, `mask` + 1 cells), or 2^32-1 when no valid hint exists
+__device__ inline uint32_t hint_find(const uint8_t* arena, const uint64_t* cells, uint32_t mask, uint32_t Y) {
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  const uint32_t hmask = ah->hint_mask;
+  if (hmask == 0 || Y == 0 || ah->y0_zeroed) return 0xFFFFFFFFu;
+  const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
+  const uint4 e = ah->hints[hint_index(base, Y, hmask)];
+  if (e.x != Y || e.y != base || e.z > mask) return 0xFFFFFFFFu;
+  return cell_key(cells[e.z]) == Y ? e.z : 0xFFFFFFFFu;
+}
+__device__ inline void hint_put(const uint8_t* arena, const uint64_t* cells, uint32_t Y, uint32_t pos) {
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  const uint32_t hmask = ah->hint_mask;
+  if (hmask == 0 || Y == 0) return;
+  const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
+  ah->hints[hint_index(base, Y, hmask)] = uint4{Y, base, pos, 0u};
+}
+
 struct LongProbe {
   bool need;
   const uint64_t* cells;
@@ -333,8 +371,9 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
                                      bool* deferred, LongProbe* lp, bool dbg_noticket = false, bool no_ret = false,
-                                     bool exists_only = false, uint64_t* where_out = nullptr) {
+                                     bool exists_only = false, uint64_t* where_out = nullptr, uint32_t budget = PROBE_BUDGET) {
   // where_out (writers, y != 0): the cell the op ended at, as an index into the arena's 8-byte cells (k_set_fold)
+  // budget (MODE 1): cells the lane probes on its own
   uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
@@ -349,7 +388,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
       if (cell_key(c) == Y) { result = cell_val(c); break; }
       if (c == 0) break;
       pos = (pos + 1) & mask;
-      if (MODE && step >= PROBE_BUDGET) { *lp = LongProbe{true, cells, mask, pos}; return 0; }
+      if (MODE && step >= budget) { *lp = LongProbe{true, cells, mask, pos}; return 0; }
     }
   } else if (Y != 0) {
     uint64_t c = cells[pos];
@@ -396,7 +435,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
       }
       if (++steps > mask) { *deferred = true; return 0; }  // no empty cell at all: let prep grow it
       pos = (pos + 1) & mask;
-      if (MODE && steps > PROBE_BUDGET) { *lp = LongProbe{true, cells, mask, pos}; return 0; }
+      if (MODE && steps > budget) { *lp = LongProbe{true, cells, mask, pos}; return 0; }
       c = cells[pos];
     }
     uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
@@ -426,7 +465,11 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         // callers without results only.
         const unsigned long long dv = (unsigned long long)(OP == OP_INCR ? V : 0u - V) << 32;
         const uint64_t old = atomicAdd(reinterpret_cast<unsigned long long*>(&cells[pos]), dv);
-        if (cell_key(old) == 0) { result = cell_val(old) + (OP == OP_INCR ? V : 0u - V); break; }
+        if (cell_key(old) == 0) {
+          result = cell_val(old) + (OP == OP_INCR ? V : 0u - V);
+          if (result == 0) reinterpret_cast<ArenaHead*>(arena)->y0_zeroed = 1;       // (a (0,0) cell is an empty cell: hints off)
+          break;
+        }
         atomicAdd(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull - dv);
         c = old;
       }
@@ -434,7 +477,11 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         uint32_t nv = OP == OP_INCR ? cell_val(c) + V : OP == OP_DECR ? cell_val(c) - V : V;
         uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]),
                                   (unsigned long long)c, (unsigned long long)pack_cell(0, nv));
-        if (prev == c) { result = nv; break; }
+        if (prev == c) {
+          result = nv;
+          if (nv == 0 && c != 0) reinterpret_cast<ArenaHead*>(arena)->y0_zeroed = 1;   // (0, v) -> (0, 0): hints off (ArenaHead)
+          break;
+        }
         c = prev;
         continue;
       }
@@ -450,7 +497,8 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
                                      uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false,
-                                     bool no_ret = false, bool exists_only = false, uint64_t* where_out = nullptr) {
+                                     bool no_ret = false, bool exists_only = false, uint64_t* where_out = nullptr,
+                                     uint32_t budget = PROBE_BUDGET) {
   uint4 s;
   DirSlot* d = dir_find(dir, dmask, X, &s);
   if (!d || s.z == 0) {
@@ -458,7 +506,7 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
     return 0;
   }
   return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket, no_ret,
-                                      exists_only, where_out);
+                                      exists_only, where_out, budget);
 }
 
 #ifndef SMX_APPLY_SGPRS
@@ -468,7 +516,9 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
 // clustered table (dense ids) are short lists in which nearly every op walks 10^3..10^5 cells; lane per op, a wave then
 // takes its 64 long probes one after the other while most of the chip has nothing to do -- the second retry of a dense
 // batch took 4 ms for 4 500 ops.
-template <int OP, bool WPO = false>
+// HM: 0 the matrix has no hint table (ArenaHead; the instantiation every scrambled-id stream runs: nothing of it is compiled in),
+//     1 it has one, 2 look (the wave-per-op kernel: clustered tables only)
+template <int OP, bool WPO = false, int HM = 0>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -480,6 +530,8 @@ __device__ __forceinline__ void apply_body(
   // (64-bit trip counter: with n > 2^31 ops and a grid that covers them all, t0 + the grid's size wraps around in 32 bits
   //  and the ops at the front would be applied a SECOND time -- round 3, found by the 2^31 + 2^27-op batch test)
   const uint64_t n_lanes = WPO ? (uint64_t)n * 64u : (uint64_t)n;
+  const bool has_hints = HM == 1 || (HM == 2 && reinterpret_cast<const ArenaHead*>(arena)->hint_mask != 0);       // (wave-uniform)
+  const uint32_t budget = has_hints ? HINT_BUDGET : PROBE_BUDGET;
   for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n_lanes; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
     const uint64_t tl = t064 + threadIdx.x;
     const uint32_t t = WPO ? (uint32_t)(tl >> 6) : (uint32_t)tl;
@@ -496,22 +548,40 @@ __device__ __forceinline__ void apply_body(
       V = OP != OP_GET ? vs[at] : 0u;
       d = dir_find(dir, dmask, xs[at], &s);
       if (!d || s.z == 0) deferred = (OP != OP_GET);      // get on an absent row: 0, creates nothing (S1)
-      else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp);
+      else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp, false, false, false, nullptr, budget);
     }
-    if (OP != OP_GET && !WPO) {                           // (the host's evidence for "this table is clustered")
-      const uint64_t lm = __ballot(lp.need);
-      if (lm && __lane_id() == 0) atomicAdd(&ctl->n_long_ops, (uint32_t)__popcll(lm));
+    // a probe that has used up its budget: is the key's cell remembered?  (ArenaHead: dense ids)
+    // was_long: the evidence for "this table is clustered" -- a probe of more than PROBE_BUDGET cells, whatever the budget was
+    bool was_long = lp.need && !has_hints;
+    if (has_hints && lp.need) {
+      const uint32_t p = hint_find(arena, lp.cells, lp.mask, Y);
+      if (p != 0xFFFFFFFFu) {
+        was_long = ((p - Y) & lp.mask) > PROBE_BUDGET;
+        lp.need = false;
+        r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
+      }
     }
-    // (a wave per op: one op in 64 is looked at, and counts for 64 -- the evidence for "not clustered any more")
-    if (OP != OP_GET && WPO && live && (t & 63u) == 0 && lp.need) atomicAdd(&ctl->n_long_ops, 64u);
+    uint32_t p_coop = PROBE_NONE;                           // where the wave-cooperative probe ended
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
       const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
       if (lp.need) {
         lp.need = false;
-        if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; }   // neither the key nor an empty cell: prep grows the row
-        else r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
+        if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; was_long = true; }   // neither the key nor an empty cell: prep grows the row
+        else {
+          if (has_hints) was_long = ((p - Y) & lp.mask) > PROBE_BUDGET;
+          r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
+          p_coop = p;
+        }
       }
     }
+    if (OP != OP_GET && !WPO) {                           // (the host's evidence for "this table is clustered")
+      const uint64_t lm = __ballot(was_long);
+      if (lm && __lane_id() == 0) atomicAdd(&ctl->n_long_ops, (uint32_t)__popcll(lm));
+    }
+    // (a wave per op: one op in 64 is looked at, and counts for 64 -- the evidence for "not clustered any more")
+    if (OP != OP_GET && WPO && live && (t & 63u) == 0 && was_long) atomicAdd(&ctl->n_long_ops, 64u);
+    // the key sits there (found, or just inserted): remembered for the next op that names it (ArenaHead)
+    if (has_hints && p_coop != PROBE_NONE && !deferred && cell_key(row_cells(arena, s.z)[p_coop]) == Y) hint_put(arena, row_cells(arena, s.z), Y, p_coop);
     if (live && !deferred) out[j] = r;
     if (OP != OP_GET) {
       // one list reservation per WORKGROUP: every atomic instruction on this one word queues at the
@@ -534,12 +604,12 @@ __device__ __forceinline__ void apply_body(
 }
 
 // (pinned to the 80-SGPR budget like k_apply_agg: the writers compiled to 97-100 SGPRs, over the residency cliff)
-template <int OP>
+template <int OP, bool HINTS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS))) void k_apply(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
-  apply_body<OP>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+  apply_body<OP, false, HINTS ? 1 : 0>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 // The keys of the listed ops -- DISTINCT keys (k_dedup_keys) -- inserted with value 0 where they do not exist (an incr by 0:
@@ -721,7 +791,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
-  apply_body<OP, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+  apply_body<OP, true, 2>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 // ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
@@ -768,7 +838,9 @@ constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/
 #ifndef SMX_AGG_SGPRS
 #define SMX_AGG_SGPRS 80
 #endif
-template <int OP, uint32_t ST = 1, bool RET = true>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare); RET: results wanted
+// CLU: the instantiation for clustered tables with a hint table (ArenaHead) -- the slow path asks for the hint after HINT_BUDGET
+// cells instead of walking PROBE_BUDGET dependent loads first (a tile waits for its slowest lane)
+template <int OP, uint32_t ST = 1, bool RET = true, bool CLU = false>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare); RET: results wanted
 __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_apply_agg(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -883,8 +955,18 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
         LongProbe lp{false, nullptr, 0, 0};
-        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5, !RET);
-        if (lp.need) { deferred = true; ctl->n_long = 1; }
+        uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5, !RET,
+                                                         false, nullptr, CLU ? HINT_BUDGET : PROBE_BUDGET);
+        if (lp.need) {
+          // (round 4) ... unless the key's cell is remembered (ArenaHead): then this is a hit like any other.  One hinted key in
+          // 256 counts for 256 long probes: the host's evidence that the table is still clustered
+          const uint32_t p = CLU ? hint_find(arena, lp.cells, lp.mask, (uint32_t)(kk[q] >> 32)) : 0xFFFFFFFFu;
+          if (CLU && p != 0xFFFFFFFFu) {
+            uint32_t* vp = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(&lp.cells[p])) + 1;
+            res = OP == OP_INCR ? atomicAdd(vp, tot[q]) + tot[q] : atomicSub(vp, tot[q]) - tot[q];
+            if (((tid ^ blockIdx.x) & 255u) == 0) atomicAdd(&ctl->n_long_ops, 256u);
+          } else { deferred = true; ctl->n_long = 1; }
+        }
         old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
       }
       l_sum[hh[q]] = old[q];                                  // the cell's value before the tile

@@ -625,6 +625,10 @@ struct Matrix {
   // clustered rows: set for good once a batch has shown long probe sequences (dense ids); SMATRIX_CLUSTERED=1 / 0 forces it
   bool clustered = false, clustered_forced = false;
   uint32_t clustered_quiet = 0;         // chained batches in a row whose (sampled) count of long probes stayed below 1/256 of the batch
+  // where far-from-home keys sit (smx_kernels.hpp ArenaHead): 2^hint_lg entries of 16 bytes, allocated when the tables turn out
+  // clustered; SMATRIX_HINT_LG (0: no hints)
+  uint4* d_hints = nullptr;
+  uint32_t hint_lg = 22;
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   DevBuf<unsigned long long> home_bits; // chunked growth in two passes: per 64 new slots, which of them hold cells that stayed at home
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
@@ -727,6 +731,19 @@ void grow_directory(Matrix* m, uint32_t factor, hipStream_t s) {
   m->st.dir_grown++;
 }
 
+// the hint table of a clustered matrix (ArenaHead); the words in unit 0 of the arena are what the kernels read
+void ensure_hints(Matrix* m, hipStream_t s) {
+  if (m->d_hints || m->hint_lg == 0) return;
+  const size_t bytes = (size_t)16 << m->hint_lg;
+  dev_malloc(&m->d_hints, bytes);
+  zero_async(m->d_hints, bytes, s);
+  struct { uint32_t mask; uint4* p; } __attribute__((packed)) w = {(1u << m->hint_lg) - 1u, m->d_hints};
+  static_assert(sizeof(w) == 12 && offsetof(ArenaHead, hint_mask) == 4 && offsetof(ArenaHead, hints) == 8, "ArenaHead layout");
+  HIP_OK(hipMemcpyAsync(m->arena.base + offsetof(ArenaHead, hint_mask), &w, sizeof(w), hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));                         // (`w` is on the stack)
+  if (m->trace_rounds) fprintf(stderr, "[smatrix] clustered tables: hint table of 2^%u entries\n", m->hint_lg);
+}
+
 template <int OP>
 void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                   const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
@@ -737,6 +754,10 @@ void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, con
     HIP_OK(hipGetLastError());
     return;
   }
+  if (m->d_hints)      // (the instantiation that asks the hint table after HINT_BUDGET cells: ArenaHead)
+    hipLaunchKernelGGL((k_apply<OP, true>), dim3(blocks_for(n)), dim3(256), 0, s, m->d_ctl, m->d_dir,
+                       m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
+  else
   hipLaunchKernelGGL((k_apply<OP>), dim3(blocks_for(n)), dim3(256), 0, s, m->d_ctl, m->d_dir,
                      m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
   HIP_OK(hipGetLastError());
@@ -755,6 +776,8 @@ void launch_apply_agg(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx,
       hipLaunchKernelGGL((k_apply_agg<OP, 1, false>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   } else if (m->in_stride == 3) {
     hipLaunchKernelGGL((k_apply_agg<OP, 3>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+  } else if (m->d_hints && m->clustered) {
+    hipLaunchKernelGGL((k_apply_agg<OP, 1, true, true>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   } else {
     hipLaunchKernelGGL((k_apply_agg<OP>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   }
@@ -1368,13 +1391,15 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         HIP_OK(hipMemcpyAsync(&m->d_ctl->spec_failed, &zero, 4, hipMemcpyHostToDevice, s));
       }
       if (m->trace_rounds)
-        fprintf(stderr, "[smatrix] batch %llu chain: ops=%u deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u\n",
+        fprintf(stderr, "[smatrix] batch %llu chain: ops=%u deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u | long probes %u%s\n",
                 (unsigned long long)m->st.batches, cur_n, nd_chain0, c.spec_nt0, (unsigned long long)c.spec_gu0, c.spec_nrebal0,
-                c.spec_failed, c.n_defer, c.n_tasks, c.dir_used);
+                c.spec_failed, c.n_defer, c.n_tasks, c.dir_used, c.n_long_ops, m->clustered ? " (clustered)" : "");
       // clustered mode goes off again after 8 chained batches in a row with hardly a long probe (the ids have changed their
       // nature: the wave-per-op pass in front of prep costs a scrambled-id batch 1.2 ms)
       if (!m->clustered_forced && m->clustered) {
-        m->clustered_quiet = (uint64_t)c.n_long_ops * 256 < n ? m->clustered_quiet + 1 : 0;
+        // (with a hint table the folding kernel finishes most far hits itself and counts (tile, key) ENTRIES, one in 256: a
+        //  hot far key is one entry per tile, not thousands of ops -- the bar is lower by that much)
+        m->clustered_quiet = (uint64_t)c.n_long_ops * (m->d_hints ? 4096 : 256) < n ? m->clustered_quiet + 1 : 0;
         if (m->clustered_quiet >= 8) m->clustered = false;
       }
       if (nd_chain0 == 0) { structure_stable = true; break; }  // round 0 deferred nothing: the rest of the chain ran empty
@@ -1404,6 +1429,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // clustered: percents of a batch needed the wave-cooperative probe (dense ids: 4-5 %; any large table at load 1/2 has a few
     // sequences beyond the budget -- the first batches of the scrambled stream do -- and must not switch it on)
     if (!m->clustered_forced && !m->clustered && (uint64_t)m->h_ctl->n_long_ops * 64 >= n) { m->clustered = true; m->clustered_quiet = 0; }
+    if (m->clustered) ensure_hints(m, s);
 
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
@@ -1717,6 +1743,8 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_COLD_SHARE")) m->cold_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_CLUSTERED")) { m->clustered = *a != '0'; m->clustered_forced = true; }
   if (const char* a = getenv("SMATRIX_WPO_MAX")) m->wpo_max = (uint32_t)strtoul(a, nullptr, 10);
+  if (const char* a = getenv("SMATRIX_HINT_LG")) m->hint_lg = std::min(28u, (uint32_t)strtoul(a, nullptr, 10));
+  if (m->clustered) ensure_hints(m, m->stream);
   if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
@@ -1765,6 +1793,7 @@ void smatrix_close(smatrix_t* self) {
       m->arena.destroy();
       clk.lap("arena unmapped");
       if (m->d_dir) (void)hipFree(m->d_dir);
+      if (m->d_hints) (void)hipFree(m->d_hints);
       if (m->d_ctl) (void)hipFree(m->d_ctl);
       if (m->h_ctl) (void)hipHostFree(m->h_ctl);
       if (m->d_small) (void)hipFree(m->d_small);
