@@ -1,4 +1,5 @@
 """The kernels of the last four write steps of a rocprofv3 kernel trace (argv[1]), in launch order: name and duration in us."""
+import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
 idx = [i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'] and t['Grid_Size_X'] == '8388608']
