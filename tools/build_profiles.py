@@ -16,7 +16,7 @@ def kernel_source_sha16():
 
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 raw = open(os.path.join(G, "prof_pmc_raw.txt")).read()
-AGG, GET = "smx::k_apply_agg<2, 1u, true>", "smx::k_apply<0>"
+AGG, GET = "smx::k_apply_agg<2, 1u, true, false>", "smx::k_apply<0, false>"   # (the instantiations of a matrix without a hint table)
 
 
 def val(kern, grid, ctr):
@@ -120,7 +120,7 @@ growth_us = 0.0
 names = []
 for ln in tl.splitlines():
     m = re.match(r"\s*([\d.]+) us\s+\+\s*([\d.]+)\s+(\S+)", ln)
-    if m and not m.group(3).startswith("smx::k_apply_agg") and m.group(3) != "smx::k_apply<0>" and "copyBuffer" not in m.group(3):
+    if m and not m.group(3).startswith("smx::k_apply_agg") and m.group(3) != GET and "copyBuffer" not in m.group(3):
         names.append((m.group(3), float(m.group(2))))
 # critical path of the growth round: prep, plan, the longer of {three in-LDS rehash kinds in sequence} and {map, move, finish, zero on the
 # helper stream}, commit, advance, retry, prep
@@ -128,7 +128,7 @@ def dur(prefix):
     return sum(v for k, v in names if k.startswith(prefix))
 lds = dur("smx::k_grow_lds")
 chunked = dur("smx::k_grow_map") + dur("smx::k_grow_move") + dur("smx::k_grow_finish") + dur("smx::k_grow_zero")
-crit = dur("smx::k_prep") + dur("smx::k_grow_plan") + max(lds, chunked) + dur("smx::k_grow_commit") + dur("smx::k_round_advance") + dur("smx::k_apply<2>")
+crit = dur("smx::k_prep") + dur("smx::k_grow_plan") + max(lds, chunked) + dur("smx::k_grow_commit") + dur("smx::k_round_advance") + dur("smx::k_apply<2")
 steady = b.get("steady_state_all_hits", {})
 ins = agg["atom"] - 15.0e6                                           # tickets + claims beyond one atomic per (tile, key) entry (census: 15.0 M entries)
 floor_agg = t_agg * 1e3
@@ -148,7 +148,7 @@ lines_f = [
  "  read misses (TCC_MISS)                      %6.2f M   / %.1f G/s = %.3f ms   (measured %.3f ms)" % (get["miss"] / 1e6, R, floor_get, kg),
  "growth round of a steady batch (kernel timeline of the last growing step of the same trace, critical path):",
  "  prep %.0f + plan %.0f + max(in-LDS rehash x3 %.0f, chunked passes %.0f) + commit %.0f + advance %.0f + retry %.0f us = %.3f ms"
- % (dur("smx::k_prep"), dur("smx::k_grow_plan"), lds, chunked, dur("smx::k_grow_commit"), dur("smx::k_round_advance"), dur("smx::k_apply<2>"), crit / 1e3),
+ % (dur("smx::k_prep"), dur("smx::k_grow_plan"), lds, chunked, dur("smx::k_grow_commit"), dur("smx::k_round_advance"), dur("smx::k_apply<2"), crit / 1e3),
  "",
  "floor of the step with every kernel AT its transaction floor and no idle time:  %.3f + %.3f + %.3f = %.3f ms" % (floor_agg, floor_get, crit / 1e3, floor_agg + floor_get + crit / 1e3),
  "measured: %.3f ms per step over the timed steps (%.2f G mixed ops/s); all-hit replay %.3f ms" % (b["ms_per_step"], b["value"] / 1e3, steady.get("ms_per_step", float("nan"))),

@@ -4,7 +4,7 @@ d = sys.argv[1]
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
 i0 = next(i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'])
-i1 = next(i for i, t in enumerate(tr) if i > i0 and 'k_apply<0>' in t['Kernel_Name'])
+i1 = next(i for i, t in enumerate(tr) if i > i0 and 'k_apply<0' in t['Kernel_Name'])
 agg = {}; cnt = {}
 for t in tr[i0:i1]:
     n = t['Kernel_Name'].split('(')[0].replace('void ', '')[:40]

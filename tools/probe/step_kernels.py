@@ -8,6 +8,6 @@ for i0 in idx[-4:]:
     for t in tr[i0:i0 + 60]:
         n = t['Kernel_Name'].split('(')[0].replace('void ', '').replace('smx::', '')[:28]
         if n.startswith('at::') or 'rocclr' in n: continue
-        if 'k_apply<0>' in n: break
+        if 'k_apply<0' in n: break
         out.append("%s %.0f" % (n, (int(t['End_Timestamp']) - int(t['Start_Timestamp'])) / 1e3))
     print(" | ".join(out))

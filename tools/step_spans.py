@@ -9,7 +9,7 @@ idx.append(len(tr))
 for s in range(len(idx) - 1):
     seg = tr[idx[s]:idx[s + 1]]
     # the step ends with its get kernel
-    e = max(i for i, t in enumerate(seg) if 'k_apply<0>' in t['Kernel_Name']) if any('k_apply<0>' in t['Kernel_Name'] for t in seg) else len(seg) - 1
+    e = max(i for i, t in enumerate(seg) if 'k_apply<0' in t['Kernel_Name']) if any('k_apply<0' in t['Kernel_Name'] for t in seg) else len(seg) - 1
     seg = seg[:e + 1]
     t0 = int(seg[0]['Start_Timestamp']); t1 = int(seg[-1]['End_Timestamp'])
     busy = sum(int(t['End_Timestamp']) - int(t['Start_Timestamp']) for t in seg)
