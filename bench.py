@@ -908,6 +908,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-lg", type=int, default=26)
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events (A/B of the overhead)")
+    ap.add_argument("--default-stream", action="store_true", help="N=1: issue the batches on the NULL stream (the library then waits for every call; A/B)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded path: one blocking apply_dev per op batch")
     ap.add_argument("--no-comm-thread", action="store_true", help="sharded path: issue the exchange from the main thread")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for test rigs)")
@@ -1016,6 +1017,12 @@ def main():
     ones = torch.ones(B, dtype=torch.int32, device=dev)
     out_i = torch.empty(B, dtype=torch.int32, device=dev)
     out_g = torch.empty(B, dtype=torch.int32, device=dev)
+    if not sharded and not args.default_stream:
+        # The batch calls are asynchronous on a caller's stream (include/smatrix_batch.h); on the NULL stream the library waits for
+        # each call to finish, and the host's time between a get batch and the next incr batch (26 us of a 2.4 ms step on the
+        # builder's boxes, more on slower hosts) is then idle time on the GPU.  The timed region is fenced with
+        # torch.cuda.synchronize() either way.
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     stream = torch.cuda.current_stream().cuda_stream
     for s in range(ring):
         gen.fill_device(s * B, B, xs[s].data_ptr(), ys[s].data_ptr(), stream)

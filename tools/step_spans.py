@@ -6,6 +6,7 @@ f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
 idx = [i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'] and t['Grid_Size_X'] == '8388608']
 idx.append(len(tr))
+prev_end = None
 for s in range(len(idx) - 1):
     seg = tr[idx[s]:idx[s + 1]]
     # the step ends with its get kernel
@@ -19,6 +20,8 @@ for s in range(len(idx) - 1):
         by[n] = by.get(n, 0) + (int(t['End_Timestamp']) - int(t['Start_Timestamp'])) / 1e3
     rounds = sum(1 for t in seg if 'k_prep' in t['Kernel_Name'])
     top = sorted(by.items(), key=lambda kv: -kv[1])[:5]
-    print("step %2d: span %8.1f us  busy %8.1f  idle %7.1f  kernels %4d rounds %2d | %s" % (
-        s, (t1 - t0) / 1e3, busy / 1e3, (t1 - t0 - busy) / 1e3, len(seg), rounds,
+    # `since` = from the end of the previous step's get kernel to this step's first kernel: the host's time between two steps
+    print("step %2d: since %6.1f  span %8.1f us  busy %8.1f  idle %7.1f  kernels %4d rounds %2d | %s" % (
+        s, (t0 - prev_end) / 1e3 if prev_end else 0.0, (t1 - t0) / 1e3, busy / 1e3, (t1 - t0 - busy) / 1e3, len(seg), rounds,
         "  ".join("%s %.0f" % (k[:18], v) for k, v in top)))
+    prev_end = t1
