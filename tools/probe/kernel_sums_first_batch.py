@@ -3,7 +3,8 @@ import csv, glob, sys
 d = sys.argv[1]
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
-i0 = next(i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'])
+# (since round 4 a large batch into an empty matrix starts with k_iota, not with the folding kernel)
+i0 = next(i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'] or 'k_iota' in t['Kernel_Name'])
 i1 = next(i for i, t in enumerate(tr) if i > i0 and 'k_apply<0' in t['Kernel_Name'])
 agg = {}; cnt = {}
 for t in tr[i0:i1]:
