@@ -934,6 +934,14 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         fast |= 1u << q;
       }
     }
+    // (round 4) The commonest INSERT rides the same pipeline: the key's home cell is EMPTY and the row is a small one (its
+    // `used` word is the ticket counter).  Its ticket add is issued beside the hits' adds -- all returning atomics of the lane in
+    // flight together -- and the claim follows in the next stage; the per-op body did the same steps one dependent round trip after
+    // the other, after a second directory look-up and a second load of the cell, with a quarter of the lanes active.  Same
+    // protocol as apply_row: a snapshot that shows the row at the reference's threshold defers at once (src/smatrix.c:346), a
+    // ticket above the threshold is given back and defers, a claim lost to another tile gives the ticket back and takes the
+    // general path (the cell may hold this very key by now).
+    uint32_t ins = 0, full = 0;
 #pragma unroll
     for (uint32_t q = 0; q < AGG_OPT; q++) {
       if (!(fast & (1u << q))) continue;
@@ -944,6 +952,30 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         if (!(ds[q].x & META_DIRTY)) dir[fmix32((uint32_t)kk[q]) & dmask].meta = ds[q].x | META_DIRTY;
       } else {
         fast &= ~(1u << q);
+        if (dbg == 0 && cc[q] == 0 && meta_lg(ds[q].x) < BIG_LG) {
+          if (ds[q].w > (1u << meta_lg(ds[q].x)) / 2u) full |= 1u << q;
+          else { old[q] = atomicAdd(&dir[fmix32((uint32_t)kk[q]) & dmask].used, 1u); ins |= 1u << q; }
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < AGG_OPT; q++) {
+      if (!(ins & (1u << q))) continue;
+      DirSlot* d = &dir[fmix32((uint32_t)kk[q]) & dmask];
+      if (old[q] > (1u << meta_lg(ds[q].x)) / 2u) {
+        atomicSub(&d->used, 1u);
+        full |= 1u << q;
+      } else {
+        // claim the cell AND apply the tile's total in one CAS (apply_row: :354-356 then :241 / :252)
+        const uint32_t first = OP == OP_DECR ? 0u - tot[q] : tot[q];
+        const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(cp[q]), 0ull, (unsigned long long)pack_cell((uint32_t)(kk[q] >> 32), first));
+        if (prev == 0) {
+          old[q] = 0;                                        // the cell's value before the tile
+          fast |= 1u << q;
+          if (!(ds[q].x & META_DIRTY)) d->meta = ds[q].x | META_DIRTY;
+        } else {
+          atomicSub(&d->used, 1u);
+        }
       }
     }
 #pragma unroll
@@ -951,7 +983,9 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
       if (!(have & (1u << q))) continue;
       bool deferred = false;
       if (dbg == 4 && !(fast & (1u << q))) { old[q] = 0; fast |= 1u << q; }     // 4: the slow path (inserts, collisions) left out
-      if (!(fast & (1u << q))) {
+      if (full & (1u << q)) {
+        deferred = true;                                     // the row stands at its threshold: prep doubles it
+      } else if (!(fast & (1u << q))) {
         // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
         LongProbe lp{false, nullptr, 0, 0};
