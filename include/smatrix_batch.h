@@ -146,6 +146,7 @@ typedef struct {
   uint64_t clustered_mode;       /* 1 once a write batch had >= 1/64 of its ops finished by the wave-cooperative probe (unscrambled ids: long runs
                                     under the reference's identity hash): large rows are then doubled in two passes, retry lists run a wave per op */
   uint64_t set_located_by_fold;  /* set batches that round 0 completed: their entries' cells were the ones k_set_fold had found (no locate pass) */
+  uint64_t flush_snapshots_refused; /* flushes that could not get their snapshot buffer on the device and wrote under the matrix lock instead */
   /* profiling (smatrix_profile): HIP-event time, launches and ops of the round-0 op kernel,
    * indexed by op code (SMATRIX_OP_GET/SET/INCR/DECR) */
   double   kernel_ms[4];

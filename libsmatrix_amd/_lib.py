@@ -17,7 +17,7 @@ class Stats(C.Structure):
         "rows", "dir_slots", "arena_units", "arena_mapped", "arena_free_units", "batches", "rounds",
         "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced", "long_probe_rounds", "scalar_cache_hits", "scalar_cache_flushes",
         "scalar_cache_flushed_cells", "bulk_rounds", "bulk_ops", "file_flushes", "file_rows_written", "file_leaked_bytes",
-        "file_compactions", "spec_chains", "spec_refused", "file_bg_flushes", "cold_starts", "cold_keys", "clustered_mode", "set_located_by_fold")] + [
+        "file_compactions", "spec_chains", "spec_refused", "file_bg_flushes", "cold_starts", "cold_keys", "clustered_mode", "set_located_by_fold", "flush_snapshots_refused")] + [
         ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
 
 

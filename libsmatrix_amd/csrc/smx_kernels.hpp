@@ -67,8 +67,23 @@ constexpr uint32_t SUB_UNITS = SUBS * 64 / 128;
 struct SubCtr { uint32_t cnt, quota, pad[14]; };
 static_assert(sizeof(SubCtr) == 64, "one sub-counter per 64-byte line");
 
+// Rows of >= 2^HOME_LG cells carry an AT-HOME BITMAP behind their cells (and sub-counter lines): one bit per cell, set iff the
+// cell holds a key whose home is that very slot (key mod size == slot, key != 0).  Row tables keep the reference's identity
+// hash (src/smatrix.c:366), so dense ids build long runs of such cells, and a key that wraps onto a run walks to its end
+// (src/smatrix.c:369-377).  A key whose home cell holds ANOTHER key can only sit in a cell that is NOT at home, so a probe may
+// step over set bits 64 cells per 8-byte load without looking at the cells.  The bitmap is an accelerator, never a structure:
+// a SET bit is always true (keys never leave their cell; key 0 -- whose (0,v) cell can turn back into an empty one, quirk
+// Q1 -- never gets one), a CLEAR bit says nothing (the cell is loaded).  Bits are set by the inserting kernels of clustered
+// matrices, written whole by growth (k_grow_move_home, k_grow_lds) and by k_home_rebuild; blocks are handed out zeroed.  The
+// bitmap never reaches the backing file.
+#ifndef SMX_HOME_LG
+#define SMX_HOME_LG 12
+#endif
+constexpr uint32_t HOME_LG = SMX_HOME_LG;
+static_assert(HOME_LG >= 10, "the bitmap of the smallest such row fills whole 128-byte units");
+__host__ __device__ inline uint64_t home_units(uint32_t lg) { return lg >= HOME_LG ? 1ull << (lg - 10) : 0; }
 __host__ __device__ inline uint64_t block_units(uint32_t lg) {
-  return units_of_lg(lg) + (lg >= BIG_LG ? SUB_UNITS : 0);
+  return units_of_lg(lg) + (lg >= BIG_LG ? SUB_UNITS : 0) + home_units(lg);
 }
 // Endgame: with little room left an even split leaves every sub-counter one or two tickets, the patient
 // retry (own share + three others) misses most of what remains, and the row bounces through one
@@ -195,6 +210,14 @@ __device__ inline uint64_t* row_cells(uint8_t* arena, uint32_t base) {
 __device__ inline SubCtr* row_subs(uint8_t* arena, uint32_t base, uint32_t lg) {
   return reinterpret_cast<SubCtr*>(arena + ((uint64_t)base + units_of_lg(lg)) * UNIT_BYTES);
 }
+// the at-home bitmap of a row of >= 2^HOME_LG cells (one 64-bit word per 64 cells)
+__device__ inline unsigned long long* row_home(uint8_t* arena, uint32_t base, uint32_t lg) {
+  return reinterpret_cast<unsigned long long*>(arena + ((uint64_t)base + units_of_lg(lg) + (lg >= BIG_LG ? SUB_UNITS : 0)) * UNIT_BYTES);
+}
+// the same from a table's cells and mask (what a LongProbe carries)
+__device__ inline const unsigned long long* cells_home(const uint64_t* cells, uint32_t mask) {
+  return reinterpret_cast<const unsigned long long*>(cells + (uint64_t)mask + 1u) + (mask + 1u >= (1u << BIG_LG) ? SUBS * 8u : 0u);
+}
 __device__ inline uint32_t subs_sum(const SubCtr* sc) {
   uint32_t t = 0;
   for (uint32_t k = 0; k < SUBS; k++) t += __hip_atomic_load(&sc[k].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -294,6 +317,11 @@ struct ArenaHead {
   uint32_t y0_zeroed;     // a y == 0 write has left a (0, 0) cell (see above)
   uint32_t hint_mask;     // entries - 1 of the hint table; 0: none
   uint4* hints;
+  // a table may hold one key TWICE (grow_fixdup_one): only after a probe chain was cut -- a (0, v) cell zeroed (y0_zeroed) or a
+  // value-0 key dropped by the loader (quirk Q4).  While neither has happened the duplicate checks of growth are skipped.
+  uint32_t twins;
+  // the at-home bitmaps (HOME_LG) are kept up to date by the inserting kernels: probes may use them (clustered matrices)
+  uint32_t home_on;
 };
 static_assert(sizeof(ArenaHead) <= 128, "unit 0 of the arena");
 constexpr uint32_t HINT_BUDGET = 8;        // cells a lane probes before it asks for a hint, when the matrix has a hint table
@@ -329,10 +357,33 @@ struct LongProbe {
 constexpr uint32_t PROBE_BUDGET = SMX_PROBE_BUDGET;
 constexpr uint32_t PROBE_NONE = 0xFFFFFFFFu;
 
+// the position of the r-th (0-based) set bit of w; r < popcount(w)
+__device__ inline uint32_t select_bit(unsigned long long w, uint32_t r) {
+  uint32_t pos = 0;
+  uint32_t lo = (uint32_t)w, c = __popc(lo);
+  if (r >= c) { r -= c; pos = 32; lo = (uint32_t)(w >> 32); }
+  c = __popc(lo & 0xFFFFu);
+  if (r >= c) { r -= c; pos += 16; lo >>= 16; }
+  c = __popc(lo & 0xFFu);
+  if (r >= c) { r -= c; pos += 8; lo >>= 8; }
+  c = __popc(lo & 0xFu);
+  if (r >= c) { r -= c; pos += 4; lo >>= 4; }
+  c = __popc(lo & 0x3u);
+  if (r >= c) { r -= c; pos += 2; lo >>= 2; }
+  if (r >= (lo & 1u)) pos += 1;
+  return pos;
+}
+
 // Called by ALL lanes of a wave together (convergent).  Lanes with `need` get the first slot at/after `pos`
 // (cyclically, at most one full turn) whose key is Y or that is empty; PROBE_NONE if the table has neither.
 // The answer is a hint for tables that are being written (the caller re-examines the slot), exact for quiescent ones.
-__device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t mask, uint32_t Y, uint32_t pos) {
+// use_home: the matrix keeps its at-home bitmaps up to date (ArenaHead::home_on).  After the first 256 cells the probe of a
+// table of >= 2^HOME_LG cells then goes on BY THE BITMAP: 64 lanes load 64 mask words (4096 cells), the cells that are not
+// at home -- the only ones that can hold Y or be empty -- are numbered across the wave (prefix sums of the popcounts) and
+// examined 64 at a time in probe order: lane i finds the owner of candidate i by a binary search over the prefix sums
+// (six shuffles) and its bit by a select in the owner's word.  A dense run costs one mask load per 4096 cells; a pile of
+// displaced cells costs what it cost before.
+__device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t mask, uint32_t Y, uint32_t pos, bool use_home = false) {
   const uint32_t lane = __lane_id();
   uint64_t todo = __ballot(need);
   uint32_t result = PROBE_NONE;
@@ -343,6 +394,7 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
         ((uint64_t)(uint32_t)__shfl((int)((uint64_t)cells >> 32), src) << 32) | (uint32_t)__shfl((int)(uint64_t)cells, src));
     const uint32_t mb = (uint32_t)__shfl((int)mask, src), yb = (uint32_t)__shfl((int)Y, src), pb = (uint32_t)__shfl((int)pos, src);
     uint32_t found = PROBE_NONE;
+    const bool by_bits = use_home && mb + 1u >= (1u << HOME_LG);           // (wave-uniform)
     for (uint64_t done = 0; done <= mb && found == PROBE_NONE; done += 256) {          // wave-uniform
       uint64_t c[4];
       bool ok[4];
@@ -356,6 +408,50 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
       for (int w = 0; w < 4; w++) {
         const uint64_t m = __ballot(ok[w] && (cell_key(c[w]) == yb || c[w] == 0));
         if (m && found == PROBE_NONE) found = (pb + (uint32_t)done + (uint32_t)w * 64u + (uint32_t)(__ffsll((unsigned long long)m) - 1)) & mb;
+      }
+      if (by_bits) break;                                                    // the rest of the walk goes by the bitmap
+    }
+    if (by_bits && found == PROBE_NONE) {
+      const unsigned long long* hb = cells_home(cb, mb);
+      const uint32_t nwords = (mb + 1u) >> 6, wmask = nwords - 1u;
+      const uint32_t start = (pb + 256u) & mb;                             // cells [pb, pb + 256) have been looked at
+      const uint32_t w0 = start >> 6;
+      // one full turn: the words w0 .. w0 + nwords (the first one from bit start & 63 on, and once more whole at the end)
+      for (uint32_t wd = 0; wd <= nwords && found == PROBE_NONE; wd += 64) {        // wave-uniform
+        const uint32_t wi = wd + lane;
+        unsigned long long cand = 0;
+        if (wi <= nwords) {
+          cand = ~hb[(w0 + wi) & wmask];
+          if (wi == 0) cand &= ~0ull << (start & 63u);
+        }
+        const uint32_t cnt = (uint32_t)__popcll(cand);
+        uint32_t incl = cnt;                                                 // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+          if ((int)lane >= d) incl += o;
+        }
+        const uint32_t excl = incl - cnt, total = (uint32_t)__shfl((int)incl, 63);
+        for (uint32_t base = 0; base < total && found == PROBE_NONE; base += 64) {  // wave-uniform
+          const uint32_t g = base + lane;
+          const bool have = g < total;
+          uint32_t own = 0;                                                  // the largest lane whose exclusive prefix is <= g
+#pragma unroll
+          for (int st = 32; st >= 1; st >>= 1) {
+            const uint32_t v = (uint32_t)__shfl((int)excl, (int)(own + st));
+            if (v <= g) own += st;
+          }
+          const uint32_t e_o = (uint32_t)__shfl((int)excl, (int)own);
+          const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(cand >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)cand, (int)own);
+          uint32_t slot = 0;
+          uint64_t c = ~0ull;
+          if (have) {
+            slot = ((((w0 + wd + own) & wmask) << 6) | select_bit(w_o, g - e_o)) & mb;
+            c = cb[slot];
+          }
+          const uint64_t m = __ballot(have && (cell_key(c) == yb || c == 0));
+          if (m) found = (uint32_t)__shfl((int)slot, __ffsll((unsigned long long)m) - 1);
+        }
       }
     }
     if ((int)lane == src) result = found;
@@ -371,9 +467,11 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
 template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t pos,
                                      bool* deferred, LongProbe* lp, bool dbg_noticket = false, bool no_ret = false,
-                                     bool exists_only = false, uint64_t* where_out = nullptr, uint32_t budget = PROBE_BUDGET) {
+                                     bool exists_only = false, uint64_t* where_out = nullptr, uint32_t budget = PROBE_BUDGET,
+                                     bool mark_home = false) {
   // where_out (writers, y != 0): the cell the op ended at, as an index into the arena's 8-byte cells (k_set_fold)
   // budget (MODE 1): cells the lane probes on its own
+  // mark_home: a key inserted into its home cell gets its bit in the row's at-home bitmap (HOME_LG; clustered matrices)
   uint32_t result = 0;
   const uint32_t lg = meta_lg(s.x);
   const uint32_t mask = (1u << lg) - 1u;
@@ -427,6 +525,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
                                   (unsigned long long)pack_cell(Y, first));
         if (prev == 0) {
           if (where_out) *where_out = ((uint64_t)s.z << 4) + pos;
+          if (mark_home && lg >= HOME_LG && pos == (Y & mask)) atomicOr(&row_home(arena, s.z, lg)[pos >> 6], 1ull << (pos & 63u));
           return first;
         }
         if (!dbg_noticket) atomicSub(ticket, 1u);        // lost the slot: give the ticket back
@@ -467,7 +566,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
         const uint64_t old = atomicAdd(reinterpret_cast<unsigned long long*>(&cells[pos]), dv);
         if (cell_key(old) == 0) {
           result = cell_val(old) + (OP == OP_INCR ? V : 0u - V);
-          if (result == 0) reinterpret_cast<ArenaHead*>(arena)->y0_zeroed = 1;       // (a (0,0) cell is an empty cell: hints off)
+          if (result == 0) { reinterpret_cast<ArenaHead*>(arena)->y0_zeroed = 1; reinterpret_cast<ArenaHead*>(arena)->twins = 1; }   // (a (0,0) cell is an empty cell: hints off)
           break;
         }
         atomicAdd(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull - dv);
@@ -479,7 +578,7 @@ __device__ inline uint32_t apply_row(DirSlot* d, const uint4 s, uint8_t* arena, 
                                   (unsigned long long)c, (unsigned long long)pack_cell(0, nv));
         if (prev == c) {
           result = nv;
-          if (nv == 0 && c != 0) reinterpret_cast<ArenaHead*>(arena)->y0_zeroed = 1;   // (0, v) -> (0, 0): hints off (ArenaHead)
+          if (nv == 0 && c != 0) { reinterpret_cast<ArenaHead*>(arena)->y0_zeroed = 1; reinterpret_cast<ArenaHead*>(arena)->twins = 1; }   // (0, v) -> (0, 0): hints off (ArenaHead)
           break;
         }
         c = prev;
@@ -498,7 +597,7 @@ template <int OP, bool PATIENT = false, int MODE = 0>
 __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t X,
                                      uint32_t Y, uint32_t V, bool* deferred, LongProbe* lp = nullptr, bool dbg_noticket = false,
                                      bool no_ret = false, bool exists_only = false, uint64_t* where_out = nullptr,
-                                     uint32_t budget = PROBE_BUDGET) {
+                                     uint32_t budget = PROBE_BUDGET, bool mark_home = false) {
   uint4 s;
   DirSlot* d = dir_find(dir, dmask, X, &s);
   if (!d || s.z == 0) {
@@ -506,7 +605,7 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
     return 0;
   }
   return apply_row<OP, PATIENT, MODE>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), deferred, lp, dbg_noticket, no_ret,
-                                      exists_only, where_out, budget);
+                                      exists_only, where_out, budget, mark_home);
 }
 
 #ifndef SMX_APPLY_SGPRS
@@ -532,6 +631,8 @@ __device__ __forceinline__ void apply_body(
   const uint64_t n_lanes = WPO ? (uint64_t)n * 64u : (uint64_t)n;
   const bool has_hints = HM == 1 || (HM == 2 && reinterpret_cast<const ArenaHead*>(arena)->hint_mask != 0);       // (wave-uniform)
   const uint32_t budget = has_hints ? HINT_BUDGET : PROBE_BUDGET;
+  // (clustered matrices: long probes go by the rows' at-home bitmaps, and inserts keep them up to date -- HOME_LG)
+  const bool use_home = HM != 0 && reinterpret_cast<const ArenaHead*>(arena)->home_on != 0;                          // (wave-uniform)
   for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n_lanes; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
     const uint64_t tl = t064 + threadIdx.x;
     const uint32_t t = WPO ? (uint32_t)(tl >> 6) : (uint32_t)tl;
@@ -548,7 +649,7 @@ __device__ __forceinline__ void apply_body(
       V = OP != OP_GET ? vs[at] : 0u;
       d = dir_find(dir, dmask, xs[at], &s);
       if (!d || s.z == 0) deferred = (OP != OP_GET);      // get on an absent row: 0, creates nothing (S1)
-      else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp, false, false, false, nullptr, budget);
+      else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp, false, false, false, nullptr, budget, use_home);
     }
     // a probe that has used up its budget: is the key's cell remembered?  (ArenaHead: dense ids)
     // was_long: the evidence for "this table is clustered" -- a probe of more than PROBE_BUDGET cells, whatever the budget was
@@ -563,7 +664,7 @@ __device__ __forceinline__ void apply_body(
     }
     uint32_t p_coop = PROBE_NONE;                           // where the wave-cooperative probe ended
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
-      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home);
       if (lp.need) {
         lp.need = false;
         if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; was_long = true; }   // neither the key nor an empty cell: prep grows the row
@@ -640,6 +741,7 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     DirSlot* d = nullptr;
     uint64_t* cells = nullptr;
     LongProbe lp{false, nullptr, 0, 0};
+    const bool use_home = reinterpret_cast<const ArenaHead*>(arena)->home_on != 0;          // (uniform; HOME_LG)
     if (live) {
       key = kin[t];
       Y = (uint32_t)key;
@@ -705,7 +807,11 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
         // the ticket is this key's until it is in: a cell lost to another key only moves the walk on
         for (uint32_t guard = 0; guard <= mask; guard++) {
           const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull, (unsigned long long)pack_cell(Y, 0u));
-          if (prev == 0) break;
+          if (prev == 0) {
+            if (use_home && mask + 1u >= (1u << HOME_LG) && pos == (Y & mask))
+              atomicOr(&row_home(arena, s.z, meta_lg(s.x))[pos >> 6], 1ull << (pos & 63u));
+            break;
+          }
           if (cell_key(prev) == Y) {                             // (not with distinct keys.  Big rows: `used` is the folded part of the
             atomicSub(&d->used, 1u);                             //  count, rowlen = used + sum(cnt) stays exact this way too)
             break;
@@ -716,9 +822,9 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     }
     // the general path (big rows: sub-counter quotas; long probe sequences: the wave-cooperative probe)
     uint32_t r = 0;
-    if (general) r = apply_row<OP_INCR, true, 1>(d, s, arena, Y, 0u, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp);
+    if (general) r = apply_row<OP_INCR, true, 1>(d, s, arena, Y, 0u, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp, false, false, false, nullptr, PROBE_BUDGET, use_home);
     while (__any(lp.need)) {
-      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home);
       if (lp.need) {
         lp.need = false;
         if (p == PROBE_NONE) deferred = true;
@@ -973,6 +1079,10 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
           old[q] = 0;                                        // the cell's value before the tile
           fast |= 1u << q;
           if (!(ds[q].x & META_DIRTY)) d->meta = ds[q].x | META_DIRTY;
+          if (CLU && meta_lg(ds[q].x) >= HOME_LG) {          // (its home cell: the row's at-home bitmap, HOME_LG)
+            const uint32_t hp = (uint32_t)(kk[q] >> 32) & ((1u << meta_lg(ds[q].x)) - 1u);
+            atomicOr(&row_home(arena, ds[q].z, meta_lg(ds[q].x))[hp >> 6], 1ull << (hp & 63u));
+          }
         } else {
           atomicSub(&d->used, 1u);
         }
@@ -990,7 +1100,7 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
         LongProbe lp{false, nullptr, 0, 0};
         uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5, !RET,
-                                                         false, nullptr, CLU ? HINT_BUDGET : PROBE_BUDGET);
+                                                         false, nullptr, CLU ? HINT_BUDGET : PROBE_BUDGET, CLU);
         if (lp.need) {
           // (round 4) ... unless the key's cell is remembered (ArenaHead): then this is a hit like any other.  One hinted key in
           // 256 counts for 256 long probes: the host's evidence that the table is still clustered
@@ -1342,7 +1452,7 @@ __device__ __forceinline__ void prep_body(
       }
     }
     while (__any(lp.need)) {                        // long sequences (dense ids): the wave finishes them (coop_probe)
-      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos);
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, reinterpret_cast<const ArenaHead*>(arena)->home_on != 0);
       if (lp.need) {
         lp.need = false;
         absent = p == PROBE_NONE || cell_key(lp.cells[p]) != Y;     // the table is quiescent here: the answer is final
@@ -2297,6 +2407,8 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
                                               uint32_t* l_cd) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
   const uint32_t tid = S::tid();
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  const bool twins = ah->twins != 0, home_on = ah->home_on != 0;      // (uniform)
   if (task->new_base == 0) return;                   // refused by the plan (scope-uniform)
   const uint32_t old_lg = task->old_lg;
   const uint32_t old_size = 1u << old_lg, new_size = 2u << old_lg, nmask = new_size - 1u;
@@ -2321,7 +2433,9 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
   }
   if (mine) atomicAdd(&l_cd[0], mine);
   S::sync();
-  // a key that a probe from its home finds in ANOTHER slot first is a duplicate (grow_fixdup_one)
+  // a key that a probe from its home finds in ANOTHER slot first is a duplicate (grow_fixdup_one) -- possible only once a
+  // probe chain has been cut (ArenaHead::twins)
+  if (twins)
   for (uint32_t q = tid; q < new_size; q += S::T) {
     const uint32_t r = l_tab[q];
     if (r == NONE) continue;
@@ -2337,11 +2451,22 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
   S::sync();
   const uint32_t dup = l_cd[1];
   if (!dup) {
+    // (the new table's at-home bitmap, HOME_LG: written whole when the matrix keeps them -- the lanes of a wave hold 64
+    //  consecutive slots; otherwise it stays all-zero as the block was handed out)
+    const bool bits = home_on && old_lg + 1 >= HOME_LG;
+    unsigned long long* hb = row_home(arena, task->new_base, old_lg + 1);
     for (uint32_t q = tid; q < new_size; q += S::T) {
       const uint32_t r = l_tab[q];
-      T[q] = r == NONE ? 0ull : l_old[r];
+      const uint64_t c = r == NONE ? 0ull : l_old[r];
+      T[q] = c;
+      if (bits) {
+        const uint64_t hm = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & nmask) == q);
+        if ((q & 63u) == 0) hb[q >> 6] = hm;
+      }
     }
     for (uint32_t p = tid; p < old_size; p += S::T) O[p] = 0;
+    if (old_lg >= HOME_LG)                                             // the retired block goes back all-zero, bitmap included
+      for (uint32_t w = tid; w < (old_size >> 6); w += S::T) row_home(arena, task->old_base, old_lg)[w] = 0;
   }
   if (tid == 0) {
     task->count = l_cd[0];
@@ -2435,7 +2560,7 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
 // congruent to its own slot, so beyond the first slot of a probe sequence it cannot be the key looked for).
 // Taken when a batch has shown long probe sequences (Matrix::clustered); scrambled ids keep the single pass.
 __device__ __forceinline__ void grow_move_home_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old,
-                                                    uint8_t* arena, unsigned long long* home_bits) {
+                                                    uint8_t* arena) {
   const uint32_t nchunks = aload(&ctl->n_chunks);
   const uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
@@ -2451,19 +2576,21 @@ __device__ __forceinline__ void grow_move_home_body(VGrid g, const Ctl* ctl, Gro
     }
     const uint32_t key = cell_key(cur), h_old = key & (old_size - 1u);
     if (cur != 0 && h_old > p) atomicMin(&k.wrap_seen, h_old);  // (a wrapped cell: a handful per table at most)
-    const bool home = cur != 0 && h_old == p && p < k.wrap_from;
+    // (key 0 is never "at home": its (0, v) cell may turn back into an empty one, quirk Q1, and a set bit must stay true)
+    const bool home = cur != 0 && key != 0 && h_old == p && p < k.wrap_from;
     const bool hi = home && (key & old_size);                   // new home = p + old_size
     if (home) row_cells(arena, k.new_base)[hi ? p + old_size : p] = pack_cell(key, p + 1);     // {key, priority}, like a moving cell
     const uint64_t lo_m = __ballot(home && !hi), hi_m = __ballot(hi);
     if (lane == 0) {
-      home_bits[k.chunk0_new + c] = lo_m;
-      home_bits[k.chunk0_new + c + (old_size >> 6)] = hi_m;
+      // the masks ARE the new table's at-home bitmap (HOME_LG): they stay behind the block for the op kernels' probes
+      unsigned long long* hb = row_home(arena, k.new_base, k.old_lg + 1);
+      hb[c] = lo_m;
+      hb[c + (old_size >> 6)] = hi_m;
     }
   }
 }
-__global__ __launch_bounds__(256) void k_grow_move_home(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena,
-                                                        unsigned long long* home_bits) {
-  grow_move_home_body(SMX_VG, ctl, tasks, map_old, arena, home_bits);
+__global__ __launch_bounds__(256) void k_grow_move_home(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena) {
+  grow_move_home_body(SMX_VG, ctl, tasks, map_old, arena);
 }
 
 // the first slot at/after i (cyclically) that no at-home cell holds (`bits`: the row's mask words), as a walk that keeps
@@ -2483,8 +2610,13 @@ struct HomeWalk {
   }
 };
 
+// (rows whose displaced cells k_grow_rest_lds places, below: the new table's bitmap fits in LDS and no cell is wrapped)
+constexpr uint32_t REST_LDS_MAX_LG = 20;                 // new table: 2^20 bits = 128 KB of LDS
+__device__ inline bool rest_by_lds(const GrowTask& k) {
+  return k.old_lg + 1 <= REST_LDS_MAX_LG && k.wrap_seen >= k.wrap_from;      // (wrap_seen < wrap_from: redone serially at the commit)
+}
 __device__ __forceinline__ void grow_move_rest_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old,
-                                                    uint8_t* arena, const unsigned long long* home_bits) {
+                                                    uint8_t* arena, bool by_lds) {
   const uint32_t nchunks = aload(&ctl->n_chunks);
   const uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
@@ -2494,9 +2626,10 @@ __device__ __forceinline__ void grow_move_rest_body(VGrid g, const Ctl* ctl, Gro
     const uint32_t old_size = 1u << k.old_lg, p = (ch - k.chunk0) * 64 + lane;
     uint64_t cur = row_cells(arena, k.old_base)[p];
     if (k.wrap_seen < k.wrap_from && lane == 0) tasks[t].dup = 1;             // (see GrowTask::wrap_seen: redone serially at the commit)
-    if (cur == 0 || ((cell_key(cur) & (old_size - 1u)) == p && p < k.wrap_from)) continue;           // empty, or placed by the first pass
+    if (by_lds && rest_by_lds(k)) continue;                                      // (k_grow_rest_lds places this row's displaced cells)
+    if (cur == 0 || (cell_key(cur) != 0 && (cell_key(cur) & (old_size - 1u)) == p && p < k.wrap_from)) continue;           // empty, or placed by the first pass
     uint64_t* T = row_cells(arena, k.new_base);
-    const unsigned long long* bits = home_bits + k.chunk0_new;
+    const unsigned long long* bits = row_home(arena, k.new_base, k.old_lg + 1);
     const uint32_t nmask = (2u << k.old_lg) - 1u;
     HomeWalk hw{bits, nmask, 0xFFFFFFFFu, 0ull};
     uint32_t i = hw.next(cell_key(cur) & nmask);
@@ -2538,16 +2671,266 @@ __device__ __forceinline__ void grow_move_rest_body(VGrid g, const Ctl* ctl, Gro
     }
   }
 }
-__global__ __launch_bounds__(256) void k_grow_move_rest(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena,
-                                                        const unsigned long long* home_bits) {
-  grow_move_rest_body(SMX_VG, ctl, tasks, map_old, arena, home_bits);
+__global__ __launch_bounds__(256) void k_grow_move_rest(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena, bool by_lds) {
+  grow_move_rest_body(SMX_VG, ctl, tasks, map_old, arena, by_lds);
+}
+
+// ---- clustered rows: the displaced cells placed through an occupancy bitmap in LDS (round 5) ---------------------------------
+// k_grow_move_rest's priority probing is correct but SLOW on clustered rows: all displaced cells of a run start at once, early
+// arrivals of low priority are evicted one by one by the cells that should have come first, and every eviction is a dependent
+// compare-and-swap -- chains of thousands (6.4-6.9 ms per dense-id step for ~70 rows, 300 000 displaced cells).  Here ONE
+// workgroup takes a row and does what smatrix_rmap_resize does (src/smatrix.c:392-404: re-insert in old slot order, each cell
+// into the first free slot from its home) on a BITMAP of the new table kept in LDS -- the at-home masks of the first pass plus
+// every cell placed so far -- so "first free slot from home" is a scan of mask words (a summary level steps over runs of full
+// words), never a walk over cells:
+//   * the old table is cut at EMPTY old slots: a cell never ends further from its new home than it sat from its old one, so
+//     the cells between two empty old slots land strictly between them (in the low or the high half) and the pieces are
+//     independent; each wave takes a range of pieces, in old slot order;
+//   * a wave collects its displaced cells in that order and places them 64 at a time.  Within a step lane l has priority over
+//     the lanes above it.  Every pending lane looks up t = its first free slot in the bitmap as it stands; lanes of a run of
+//     neighbours with the same t (a pile behind a dense run) take the following free slots in order (z = the r-th free slot
+//     from t).  A lane COMMITS -- sets its bit, stores its cell -- when no lower pending lane has the same z (it would lose the
+//     slot to it) and no lower lane that does not commit in this round has a smaller z (that lane's place is still open and
+//     may turn out to be this very slot); the others look again in the next round.  The lowest pending lane always commits.
+//     What a lane commits is exactly its place in the sequential order: everything from its home up to z is taken by then,
+//     and nobody before it takes z.
+// Rows whose new bitmap does not fit (more than 2^REST_LDS_MAX_LG cells) keep k_grow_move_rest.
+constexpr uint32_t REST_THREADS = 512, REST_WAVES = REST_THREADS / 64;     // (8 waves: bitmap + summary + 8 x 2.5 KB of staged cells stay under 160 KB)
+constexpr uint32_t REST_STAGE = 320;                     // staged cells per wave (a step takes 64; up to 4 x 64 arrive at once)
+constexpr uint32_t REST_BUCKETS = 256;                   // per wave: {slot, lowest lane that wants it}, open addressing
+__host__ __device__ inline size_t rest_lds_bytes() {
+  return ((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX_LG - 9)) + (size_t)REST_WAVES * REST_STAGE * 8 + (size_t)REST_WAVES * REST_BUCKETS * 4 + (REST_WAVES + 2) * 4;
+}
+// the first clear bit at/after slot i (cyclically) of the nw-word bitmap B; S: one bit per word of B, set when the word is full
+__device__ inline uint32_t lds_first_zero(const unsigned long long* B, const unsigned long long* S, uint32_t nw, uint32_t i) {
+  uint32_t w = i >> 6;
+  unsigned long long z = ~B[w] & (~0ull << (i & 63u));
+  for (uint32_t guard = 0; z == 0 && guard < 2 * nw + 4; guard++) {
+    w = (w + 1) & (nw - 1);
+    z = ~B[w];
+    if (z == 0) {
+      // a full word: the summary names the next word that is not (nw >= 64: every summary word is whole)
+      const uint32_t ns = nw >> 6;
+      uint32_t sw = w >> 6;
+      unsigned long long sz = ~S[sw] & (~0ull << (w & 63u));
+      for (uint32_t g2 = 0; sz == 0 && g2 <= ns; g2++) { sw = (sw + 1) & (ns - 1); sz = ~S[sw]; }
+      if (sz == 0) return 0xFFFFFFFFu;                     // (cannot happen: the table is at most half full)
+      w = (sw << 6) + (uint32_t)__ffsll(sz) - 1u;
+      z = ~B[w];                                           // (the summary may lag behind a word that has just filled up: the loop goes on)
+    }
+  }
+  return (w << 6) + (uint32_t)__ffsll(z) - 1u;
+}
+// the r-th (0-based) clear bit at/after slot t (t itself is clear)
+__device__ inline uint32_t lds_nth_zero(const unsigned long long* B, uint32_t nw, uint32_t t, uint32_t r) {
+  uint32_t w = t >> 6;
+  unsigned long long z = ~B[w] & (~0ull << (t & 63u));
+  for (uint32_t guard = 0; guard < 2 * nw + 4; guard++) {
+    const uint32_t c = (uint32_t)__popcll(z);
+    if (r < c) return (w << 6) + select_bit(z, r);
+    r -= c;
+    w = (w + 1) & (nw - 1);
+    z = ~B[w];
+  }
+  return 0xFFFFFFFFu;
+}
+
+static_assert(((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX_LG - 9)) + (size_t)REST_WAVES * REST_STAGE * 8 + (size_t)REST_WAVES * REST_BUCKETS * 4 + (REST_WAVES + 2) * 4 <= 160 * 1024,
+              "k_grow_rest_lds: the LDS of one CU");
+// dbg (measurement runs only, SMATRIX_REST_DBG): counters {steps, rounds, cells, most steps of one wave, trips, most trips of one
+// wave}; bit 0 of dbg_mode: the staged cells are dropped instead of placed (what the loads alone cost: tables wrong afterwards)
+__global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list, uint8_t* arena,
+                                                                unsigned long long* dbg, uint32_t dbg_mode) {
+  extern __shared__ unsigned long long l_rest[];
+  unsigned long long* B = l_rest;                                           // 2^(REST_LDS_MAX_LG - 6) words
+  unsigned long long* S = B + (1u << (REST_LDS_MAX_LG - 6));                // 2^(REST_LDS_MAX_LG - 12) words
+  uint64_t* stage_all = reinterpret_cast<uint64_t*>(S + (1u << (REST_LDS_MAX_LG - 12)));
+  uint32_t* scratch_all = reinterpret_cast<uint32_t*>(stage_all + REST_WAVES * REST_STAGE);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint64_t* stage = stage_all + wave * REST_STAGE;                          // {key, old slot + 1} of this wave's pending displaced cells, in old slot order
+  uint32_t* bucket = scratch_all + wave * REST_BUCKETS;
+  uint32_t* bound = scratch_all + REST_WAVES * REST_BUCKETS;                // where each wave's range of old slots begins
+  const uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
+  for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {                 // block-uniform
+    const GrowTask k = tasks[list[li]];
+    if (k.new_base == 0 || grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE || !rest_by_lds(k)) continue;
+    const uint32_t old_size = 1u << k.old_lg, omask = old_size - 1u, new_size = 2u * old_size, nmask = new_size - 1u, nw = new_size >> 6;
+    const uint64_t* O = row_cells(arena, k.old_base);
+    uint64_t* T = row_cells(arena, k.new_base);
+    const unsigned long long* hb = row_home(arena, k.new_base, k.old_lg + 1);
+    __syncthreads();                                                        // (the previous task's bitmap is done with)
+    for (uint32_t w = threadIdx.x; w < nw; w += REST_THREADS) B[w] = hb[w];
+    __syncthreads();
+    for (uint32_t sw = threadIdx.x; sw < (nw >> 6); sw += REST_THREADS) {
+      unsigned long long m = 0;
+      for (uint32_t b = 0; b < 64; b++) if (B[sw * 64 + b] == ~0ull) m |= 1ull << b;
+      S[sw] = m;
+    }
+    __syncthreads();
+    // this wave's range of old slots: from the first empty old slot at/after its nominal start to the one of the next wave
+    {
+      uint32_t b = wave * (old_size / REST_WAVES);
+      if (wave != 0) {
+        for (bool found = false; !found;) {                                 // (wave-uniform; eight 64-cell windows in flight)
+          uint64_t c[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) { const uint32_t p = b + (uint32_t)q * 64u + lane; c[q] = p < old_size ? O[p] : 1ull; }
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const uint64_t m = __ballot(c[q] == 0);
+            if (m && !found) { b += (uint32_t)q * 64u + (uint32_t)__ffsll((unsigned long long)m) - 1u; found = true; }
+          }
+          if (!found) { b += 512; if (b >= old_size) { b = old_size; found = true; } }
+        }
+      }
+      if (lane == 0) bound[wave] = b;
+      if (threadIdx.x == 0) { bound[REST_WAVES] = old_size; bound[REST_WAVES + 1] = 0; }
+    }
+    __syncthreads();
+    const uint32_t lo = bound[wave], hi = bound[wave + 1];
+    // A table whose first run continues its last one round the end (wrapped cells: GrowTask::wrap_from): the wrapped cells sit
+    // in the FIRST piece and come first in old slot order, but land among the cells of the LAST piece -- so the wave that holds
+    // the end of the table starts only when wave 0 is through (bound[REST_WAVES + 1]); all other pieces stay independent.
+    if (k.wrap_seen != 0xFFFFFFFFu && wave != 0 && hi == old_size && lo < hi)
+      while (__hip_atomic_load(&bound[REST_WAVES + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
+    uint32_t n_st = 0;                                                      // staged cells (wave-uniform)
+    uint32_t d_steps = 0, d_rounds = 0, d_trips = 0;
+    // a step: the first `cnt` staged cells (cnt <= 64), lane l = the l-th of them in old slot order
+    auto place = [&](uint32_t cnt) {
+      const bool valid = lane < cnt;
+      const uint64_t cell = valid ? stage[lane] : 0ull;                     // {key, priority}
+      uint32_t cur = cell_key(cell) & nmask;
+      bool pending = valid && !(dbg_mode & 1u);
+      d_steps++;
+      while (__any(pending)) {                                              // (wave-uniform)
+        d_rounds++;
+        uint32_t t = 0xFFFFFFFFu, z = 0xFFFFFFFFu;
+        if (pending) t = lds_first_zero(B, S, nw, cur);
+        // RUNS of pending neighbours that fill one stretch of free slots: the r-th lane of a run takes the r-th free slot from the
+        // run's base.  A run begins where the first free slot changes; two runs are one when the second one's first free slot is
+        // among the slots the first run is going to take (its base <= t <= the slot of the lane before): lanes in old slot order
+        // mostly have rising homes, and a pile behind a run of taken slots grows exactly like that.  (Valid as LOWER bounds
+        // whatever the homes are: by the time such a lane's turn comes, the lanes of its run below it have taken -- or found
+        // taken -- every free slot from the base up to its own.)
+        // (neighbours = pending lanes bound for the same HALF of the new table: a step's cells alternate between the two -- new
+        //  home = old home or old home + old size -- and the halves do not meet except at their ends)
+        const uint64_t hi_half = __ballot(pending && t >= old_size);
+        const uint64_t same = t >= old_size ? hi_half : ~hi_half;
+        const uint64_t pm = __ballot(pending) & same;
+        const uint64_t lower = pm & ((1ull << lane) - 1ull);
+        const uint32_t prev = lower ? 63u - (uint32_t)__clzll((unsigned long long)lower) : lane;   // the pending lane before this one
+        const uint32_t t_prev = (uint32_t)__shfl((int)t, (int)prev);
+        uint64_t starts = __ballot(pending && (lower == 0 || t != t_prev));                      // lanes that begin a run
+        for (;;) {                                                                               // (wave-uniform)
+          const uint64_t sb = starts & same & ((2ull << lane) - 1ull);
+          const uint32_t start_lane = sb ? 63u - (uint32_t)__clzll((unsigned long long)sb) : 0u;
+          const uint32_t r = (uint32_t)__popcll(lower & ~((1ull << start_lane) - 1ull));          // pending lanes of the run below this one
+          const uint32_t t_run = (uint32_t)__shfl((int)t, (int)start_lane);
+          z = 0xFFFFFFFFu;
+          if (pending) z = r ? lds_nth_zero(B, nw, t_run, r) : t_run;
+          const uint32_t z_prev = (uint32_t)__shfl((int)z, (int)prev), t_run_prev = (uint32_t)__shfl((int)t_run, (int)prev);
+          const uint64_t mm = __ballot(pending && lower != 0 && ((starts >> lane) & 1ull) && t >= t_run_prev && t <= z_prev);
+          if (!mm) break;
+          starts &= ~mm;
+        }
+        // RELAXATION to a fixed point.  Invariant of every pending lane: each free slot from its starting point up to (not
+        // including) its z is taken, by the time its turn comes, by a lane below it.  A lane that shares its z with a lower lane
+        // gives way: that slot is taken too by then, so its z moves on to the next free one -- the invariant holds again.  When
+        // no two pending lanes share a slot, every lane's z IS its place in the sequential order (induction over the lanes: all
+        // that is free before z is gone, and nobody below ends at z), and all of them commit at once.
+        // Who shares: an open-addressed table of {slot, lowest lane that wants it}; only lanes that give way insert again (the
+        // entry of the slot they leave keeps naming the lower lane), everybody looks at its own entry again.
+#pragma unroll
+        for (uint32_t q = 0; q < REST_BUCKETS; q += 64) bucket[q + lane] = 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t bk = 0, n_keys = (uint32_t)__popcll(__ballot(pending));
+        bool insert = pending;
+        uint64_t losers = 0;
+        for (;;) {                                                          // (wave-uniform)
+          if (insert) {
+            const uint32_t mine = (z << 6) | lane;
+            bk = ((z * 0x9E3779B1u) >> 16) & (REST_BUCKETS - 1u);
+            for (;;) {
+              const uint32_t old = atomicCAS(&bucket[bk], 0xFFFFFFFFu, mine);
+              if (old == 0xFFFFFFFFu) break;
+              if ((old >> 6) == z) { atomicMin(&bucket[bk], mine); break; }
+              bk = (bk + 1u) & (REST_BUCKETS - 1u);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const bool loser = pending && (bucket[bk] & 63u) != lane;
+          losers = __ballot(loser);
+          if (dbg && (dbg_mode & 2u) && lane == 0) { atomicAdd(&dbg[8], (unsigned long long)__popcll(losers)); atomicAdd(&dbg[9], 1ull); }
+          if (!losers) break;
+          n_keys += (uint32_t)__popcll(losers);
+          if (n_keys > REST_BUCKETS * 3u / 4u) break;                       // (the table is filling up: what is settled commits, the rest starts over)
+          insert = loser;
+          if (loser) z = lds_first_zero(B, S, nw, (z + 1u) & nmask);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // everything commits -- or, when the table ran full, the lanes below the lowest one that still shares a slot
+        const uint32_t upto = losers ? (uint32_t)__ffsll((unsigned long long)losers) - 1u : 64u;
+        if (pending && lane < upto) {
+          const unsigned long long bit = 1ull << (z & 63u);
+          const unsigned long long before = atomicOr(&B[z >> 6], bit);
+          if ((before | bit) == ~0ull) atomicOr(&S[z >> 12], 1ull << ((z >> 6) & 63u));
+          T[z] = cell;
+          pending = false;
+        }
+        if (pending) cur = t;                                               // (everything below t is taken: the next look starts there)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      // what is left moves to the front
+      const uint32_t rest = n_st - cnt;
+      uint64_t mv[(REST_STAGE + 63) / 64];
+#pragma unroll
+      for (uint32_t q = 0; q < (REST_STAGE + 63) / 64; q++) mv[q] = q * 64 + lane < rest ? stage[cnt + q * 64 + lane] : 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (uint32_t q = 0; q < (REST_STAGE + 63) / 64; q++) if (q * 64 + lane < rest) stage[q * 64 + lane] = mv[q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      n_st = rest;
+    };
+    // the range, eight chunks of 64 old slots per trip (their loads in flight together), staged four at a time
+    for (uint32_t p0 = lo; p0 < hi; p0 += 512) {                             // (wave-uniform)
+      d_trips++;
+      uint64_t c[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t p = p0 + (uint32_t)q * 64u + lane;
+        c[q] = p < hi ? O[p] : 0ull;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int q = half * 4; q < half * 4 + 4; q++) {
+          const uint32_t p = p0 + (uint32_t)q * 64u + lane;
+          const uint32_t key = cell_key(c[q]);
+          const bool displaced = c[q] != 0 && !(key != 0 && (key & omask) == p && p < k.wrap_from);      // (at-home cells were stored by the first pass)
+          const uint64_t dm = __ballot(displaced);
+          if (displaced) stage[n_st + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pack_cell(key, p + 1u);
+          n_st += (uint32_t)__popcll(dm);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (n_st >= 64) place(64);
+      }
+    }
+    if (n_st) place(n_st);
+    if (wave == 0 && lane == 0) __hip_atomic_store(&bound[REST_WAVES + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (dbg && lane == 0) {
+      atomicAdd(&dbg[0], (unsigned long long)d_steps); atomicAdd(&dbg[1], (unsigned long long)d_rounds);
+      atomicMax(&dbg[3], (unsigned long long)d_steps); atomicAdd(&dbg[4], (unsigned long long)d_trips); atomicMax(&dbg[5], (unsigned long long)d_trips);
+      atomicMax(&dbg[6], (unsigned long long)d_rounds);
+    }
+  }
 }
 
 // one wave per 64 new slots: replace the carried old-slot index by the value
 // home_bits != nullptr: the two-pass move ran (clustered rows); the duplicate check steps over at-home residents
 __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTask* tasks,
-                                                 const uint32_t* map_new, uint8_t* arena, const unsigned long long* home_bits = nullptr) {
+                                                 const uint32_t* map_new, uint8_t* arena, bool two_pass = false) {
   uint32_t nchunks = 2u * aload(&ctl->n_chunks);    // (chunked rows: the new table has twice the old one's chunks)
+  const bool twins = reinterpret_cast<const ArenaHead*>(arena)->twins != 0;     // (uniform) no chain was ever cut: no key sits twice
   uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
   uint32_t nwaves = (g.nb * blockDim.x) >> 6;
@@ -2563,11 +2946,12 @@ __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTa
       if (c != 0) {
         uint64_t o = row_cells(arena, k.old_base)[cell_val(c) - 1];
         T[q] = pack_cell(cell_key(c), cell_val(o));
+        if (!twins) continue;
         // a key that a probe from its home finds in ANOTHER slot first is a duplicate
         // (keys are stable during this kernel, only value words change)
         uint32_t nmask = new_size - 1u, i = cell_key(c) & nmask;
-        if (home_bits) {
-          const unsigned long long* bits = home_bits + k.chunk0_new;
+        if (two_pass) {
+          const unsigned long long* bits = row_home(arena, k.new_base, k.old_lg + 1);
           // (q itself is not at home unless q == i: the walk stops there at the latest)
           if (i != q && cell_key(T[i]) != cell_key(c)) {
             // (eight slots of the walk at a time, like k_grow_move_rest: keys do not change in this kernel)
@@ -2596,8 +2980,8 @@ __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTa
   }
 }
 __global__ __launch_bounds__(256) void k_grow_finish(const Ctl* ctl, GrowTask* tasks,
-                                                     const uint32_t* map_new, uint8_t* arena, const unsigned long long* home_bits) {
-  grow_finish_body(SMX_VG, ctl, tasks, map_new, arena, home_bits);
+                                                     const uint32_t* map_new, uint8_t* arena, bool two_pass) {
+  grow_finish_body(SMX_VG, ctl, tasks, map_new, arena, two_pass);
 }
 
 // A row table can hold one key twice: y=0 writes may turn the uncounted (0,v) cell back
@@ -2625,6 +3009,20 @@ __device__ inline void grow_fixdup_one(GrowTask& k, uint8_t* arena) {
   }
   k.count = used;
   for (uint32_t p = 0; p < old_size; p++) O[p] = 0;
+  // the at-home bitmaps (HOME_LG): the new one is rebuilt for the table as it now stands, the retired block's is wiped
+  if (k.old_lg + 1 >= HOME_LG) {
+    unsigned long long* hb = row_home(arena, k.new_base, k.old_lg + 1);
+    for (uint32_t w = 0; w <= (nmask >> 6); w++) {
+      unsigned long long m = 0;
+      for (uint32_t b = 0; b < 64; b++) {
+        const uint64_t c = T[w * 64 + b];
+        if (c != 0 && cell_key(c) != 0 && (cell_key(c) & nmask) == w * 64 + b) m |= 1ull << b;
+      }
+      hb[w] = m;
+    }
+  }
+  if (k.old_lg >= HOME_LG)
+    for (uint32_t w = 0; w < (old_size >> 6); w++) row_home(arena, k.old_base, k.old_lg)[w] = 0;
 }
 
 // one wave per 64 old slots: a retired block goes back to its size class's stack ZEROED
@@ -2640,6 +3038,7 @@ __device__ __forceinline__ void grow_zero_body(VGrid g, const Ctl* ctl, const Gr
     if (k.dup || k.new_base == 0) continue;          // grow_fixdup_one still needs (and then zeroes) it; refused: untouched
     const uint32_t p = (ch - k.chunk0) * 64 + lane;
     if (p < (1u << k.old_lg)) row_cells(arena, k.old_base)[p] = 0;
+    if (lane == 0) row_home(arena, k.old_base, k.old_lg)[ch - k.chunk0] = 0;       // (chunked rows have >= 2^14 cells: HOME_LG)
   }
 }
 __global__ __launch_bounds__(256) void k_grow_zero(const Ctl* ctl, const GrowTask* tasks,
@@ -2701,6 +3100,32 @@ __device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* ta
 __global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, GrowTask* tasks, DirSlot* dir, uint8_t* arena,
                                                      FreeLists fl) {
   grow_commit_body(SMX_VG, ctl, tasks, dir, arena, fl);
+}
+
+// The at-home bitmaps of all rows of >= 2^HOME_LG cells, rebuilt from the tables as they stand: run once when a matrix turns
+// out clustered (until then nobody sets bits) and after a file has been loaded into a clustered matrix.
+// k_home_list: the directory slots of such rows; k_home_rebuild: blockIdx.y = entry of that list, a wave per 64 cells.
+__global__ __launch_bounds__(256) void k_home_list(const DirSlot* dir, uint32_t dir_size, uint32_t* list, uint32_t* n_list, uint32_t cap) {
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < dir_size; h += gridDim.x * blockDim.x) {
+    const DirSlot d = dir[h];
+    if ((d.meta & META_USED) && d.base != 0 && meta_lg(d.meta) >= HOME_LG) {
+      const uint32_t at = atomicAdd(n_list, 1u);
+      if (at < cap) list[at] = h;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_home_rebuild(const DirSlot* dir, const uint32_t* list, uint32_t first, uint8_t* arena) {
+  const DirSlot d = dir[list[first + blockIdx.y]];
+  const uint32_t lg = meta_lg(d.meta), nwords = 1u << (lg - 6), mask = (1u << lg) - 1u;
+  const uint64_t* cells = row_cells(arena, d.base);
+  unsigned long long* hb = row_home(arena, d.base, lg);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nwords; w += gridDim.x * 4u) {
+    const uint32_t p = w * 64u + lane;
+    const uint64_t c = cells[p];
+    const uint64_t m = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & mask) == p);
+    if (lane == 0) hb[w] = m;
+  }
 }
 
 // big rows flagged by prep: fold the sub-counters into `used`, share out what room is left
@@ -3342,9 +3767,9 @@ __global__ __launch_bounds__(256) void k_cf_expand(uint64_t t0, uint32_t count, 
 // k_dirty_collect: every directory slot marked META_DIRTY is copied to `out` and unmarked (one list reservation per
 // workgroup).  With all != 0 every row is taken (first write of a file, compaction).
 // budget (bytes of row cells; ~0: none): the flush that snapshots its rows on the device takes only so much at a time.
-// A workgroup reserves its rows' bytes with one add on count[1..2]; a share that STARTS beyond the budget is left as
-// it is -- rows stay marked, count[3] says that more is waiting -- so one call takes the budget plus at most one
-// workgroup's rows.
+// count[0] = rows listed, count[1] = "more are waiting", count[2..3] = bytes reserved so far (one 64-bit word).
+// A workgroup reserves its rows' bytes with one add on that word; a share that STARTS beyond the budget is left as
+// it is -- rows stay marked, count[1] is set -- so one call takes the budget plus at most one workgroup's rows.
 __global__ __launch_bounds__(256) void k_dirty_collect(DirSlot* dir, uint32_t dir_size, uint32_t all, DirSlot* out,
                                                        uint32_t cap, uint32_t* count, unsigned long long budget) {
   __shared__ uint32_t l_n, l_base, l_ok;

@@ -70,6 +70,37 @@ inline hipError_t dev_free(void* p) {
   if (trace_alloc()) fprintf(stderr, "[smatrix]     free %p  %.3f ms\n", p, (mono_s() - t0) * 1e3);
   return e;
 }
+// The library's OWN stream-ordered pool, one per device (DevBuf::need_on: scratch of one batch).  Freed memory stays in it up
+// to 1 GB instead of going back to the driver at the next synchronisation.  (Round 4 raised the release threshold of the
+// device's DEFAULT pool instead -- a process-wide side effect on the host application)  nullptr when the runtime
+// refuses to create one: need_on then falls back to plain allocations.
+inline hipMemPool_t scratch_pool() {
+  static std::mutex mu;
+  static std::vector<std::pair<int, hipMemPool_t>> pools;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> g(mu);
+  for (auto& e : pools) if (e.first == dev) return e.second;
+  hipMemPoolProps props = {};
+  props.allocType = hipMemAllocationTypePinned;
+  props.handleTypes = hipMemHandleTypeNone;
+  props.location.type = hipMemLocationTypeDevice;
+  props.location.id = dev;
+  hipMemPool_t pool = nullptr;
+  if (hipMemPoolCreate(&pool, &props) != hipSuccess) { (void)hipGetLastError(); pool = nullptr; }
+  if (pool) {
+    uint64_t keep = 1ull << 30;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    (void)hipGetLastError();
+  }
+  pools.push_back({dev, pool});
+  return pool;
+}
+// what the pool retains goes back to the driver (before the library gives up on an allocation)
+inline void scratch_pool_trim() {
+  if (hipMemPool_t pool = scratch_pool()) { (void)hipMemPoolTrimTo(pool, 0); (void)hipGetLastError(); }
+}
+
 template <typename T>
 inline void dev_malloc(T** p, size_t bytes) {
   struct Tick { double t0 = mono_s(); size_t b; ~Tick() { AllocClock& c = alloc_clock(); c.n_alloc++; c.s_alloc += mono_s() - t0;
@@ -78,6 +109,7 @@ inline void dev_malloc(T** p, size_t bytes) {
   if (hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess) return;
   (void)hipGetLastError();
   chunk_pool_trim();
+  scratch_pool_trim();
   HIP_OK(hipMalloc(reinterpret_cast<void**>(p), bytes));
 }
 
@@ -279,7 +311,8 @@ struct DevBuf {
     size_t c = n;
     const double t0 = mono_s();
     static const bool use_pool = !(getenv("SMATRIX_SCRATCH_POOL") && *getenv("SMATRIX_SCRATCH_POOL") == '0');
-    if (use_pool && hipMallocAsync(reinterpret_cast<void**>(&p), c * sizeof(T), s) == hipSuccess) {
+    hipMemPool_t pool = use_pool ? scratch_pool() : nullptr;
+    if (pool && hipMallocFromPoolAsync(reinterpret_cast<void**>(&p), c * sizeof(T), pool, s) == hipSuccess) {
       pooled = true;
       AllocClock& ac = alloc_clock(); ac.n_alloc++; ac.s_alloc += mono_s() - t0;
       if (trace_alloc()) fprintf(stderr, "[smatrix]     alloc (stream-ordered) %zu bytes  %.3f ms\n", c * sizeof(T), (mono_s() - t0) * 1e3);
@@ -630,7 +663,9 @@ struct Matrix {
   uint4* d_hints = nullptr;
   uint32_t hint_lg = 22;
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
-  DevBuf<unsigned long long> home_bits; // chunked growth in two passes: per 64 new slots, which of them hold cells that stayed at home
+  unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
+  bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
+  bool home_on = false;                 // the rows' at-home bitmaps (smx_kernels.hpp HOME_LG) are kept up to date and used by the probes: host mirror of ArenaHead::home_on
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
   uint32_t cold_share = 64;             // ... and only when at least 1/cold_share of the batch is still pending (SMATRIX_COLD_SHARE).  (Not stricter: the
                                         // first chunk of the CF import has 3 M of 2^25 ops pending when its rows have been created, and needs it:
@@ -742,6 +777,44 @@ void ensure_hints(Matrix* m, hipStream_t s) {
   HIP_OK(hipMemcpyAsync(m->arena.base + offsetof(ArenaHead, hint_mask), &w, sizeof(w), hipMemcpyHostToDevice, s));
   HIP_OK(hipStreamSynchronize(s));                         // (`w` is on the stack)
   if (m->trace_rounds) fprintf(stderr, "[smatrix] clustered tables: hint table of 2^%u entries\n", m->hint_lg);
+}
+
+// a 32-bit word of ArenaHead (unit 0 of the arena)
+void arena_head_set(Matrix* m, size_t offset, uint32_t value, hipStream_t s) {
+  HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->arena.base + offset), (int)value, 1, s));
+}
+
+// The device-side helpers of a clustered matrix brought in line with m->clustered: the hint table, and the rows' at-home
+// bitmaps (smx_kernels.hpp HOME_LG) -- nobody sets bits while a matrix is not clustered, so they are rebuilt from the tables
+// as they stand at the moment it turns out to be (the tables must be quiescent: between two rounds, or after a load).
+void clustered_sync(Matrix* m, hipStream_t s) {
+  if (m->clustered) {
+    ensure_hints(m, s);
+    if (m->home_on) return;
+    if (m->dir_used) {
+      DevBuf<uint32_t> list;
+      list.need((size_t)m->dir_used + 1);
+      HIP_OK(hipMemsetAsync(m->d_small + 14, 0, 4, s));
+      hipLaunchKernelGGL(k_home_list, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_dir, m->dir_size, list.p, m->d_small + 14,
+                         m->dir_used);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipMemcpyAsync(m->h_small + 14, m->d_small + 14, 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      const uint32_t n = std::min(m->h_small[14], m->dir_used);
+      for (uint32_t first = 0; first < n; first += 32768) {
+        hipLaunchKernelGGL(k_home_rebuild, dim3(64, std::min<uint32_t>(n - first, 32768)), dim3(256), 0, s, m->d_dir, list.p, first, m->arena.base);
+        HIP_OK(hipGetLastError());
+      }
+      HIP_OK(hipStreamSynchronize(s));
+      list.release();
+      if (m->trace_rounds) fprintf(stderr, "[smatrix] clustered tables: at-home bitmaps of %u rows rebuilt\n", n);
+    }
+    arena_head_set(m, offsetof(ArenaHead, home_on), 1u, s);
+    m->home_on = true;
+  } else if (m->home_on) {
+    arena_head_set(m, offsetof(ArenaHead, home_on), 0u, s);
+    m->home_on = false;
+  }
 }
 
 template <int OP>
@@ -903,25 +976,28 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     // clustered rows (a batch has shown long probe sequences: dense ids): the move in two passes, at-home cells first
     // (smx_kernels.hpp "clustered rows")
     // (scrambled ids, same box, A/B: the two passes cost 2.475 / 2.487 ms per step against 2.447 / 2.442 for the single one)
-    const bool two_pass = m->clustered;
-    unsigned long long* bits = nullptr;
-    if (two_pass) {
-      m->home_bits.need(nc_bound + 1); bits = m->home_bits.p;
-    }
+    // (the first pass leaves the new tables' at-home bitmaps behind their blocks: the second pass, the duplicate check and,
+    //  from then on, the op kernels' long probes step over at-home cells by them -- smx_kernels.hpp HOME_LG)
+    const bool two_pass = m->clustered && m->home_on;
     hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 2048)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p,
                        two_pass ? m->arena.base : nullptr);
     if (two_pass) {
       hipLaunchKernelGGL(k_grow_move_home, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, bits);
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+      // the displaced cells: a workgroup per row on an occupancy bitmap in LDS (k_grow_rest_lds); the chunked pass behind it
+      // takes only what that kernel leaves (giant rows, rows with wrapped cells).  SMATRIX_REST_LDS=0: the chunked pass alone
+      if (m->rest_lds)
+        hipLaunchKernelGGL(k_grow_rest_lds, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 1024)), dim3(REST_THREADS), rest_lds_bytes(), sc,
+                           m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->arena.base, m->rest_dbg, m->rest_dbg_mode);
       hipLaunchKernelGGL(k_grow_move_rest, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, bits);
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, m->rest_lds);
     } else {
       hipLaunchKernelGGL(k_grow_move, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                          dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
     }
     hipLaunchKernelGGL(k_grow_finish, dim3(std::min<uint32_t>(blocks_for(nc_bound * 64), 16384)),
-                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base, bits);
+                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_new.p, m->arena.base, two_pass);
     hipLaunchKernelGGL(k_grow_zero, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                        dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
   }
@@ -960,7 +1036,9 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   // (only when the list dwarfs the directory -- the first batches of a matrix; a bulk load in progress, whose directory has
   //  grown with its rows, keeps the cheap path: one creation pass, now and then a rebuild)
   bool created_from_set = false;
-  if (nd >= m->fix_presize_min && nd / 16 >= m->dir_size) {
+  // (the scratch set is capped at 2^28 slots, so lists that may name more than 2^27 distinct rows keep the
+  //  one-factor-at-a-time growth -- a set that fills up would never let k_fix_count_rows' probe end)
+  if (nd >= m->fix_presize_min && nd / 16 >= m->dir_size && nd <= (1u << 27)) {
     uint64_t slots = 1u << 16;
     while (slots < 2ull * std::min<uint64_t>(nd, 1ull << 27)) slots <<= 1;
     m->cold_set.need_on(slots, s);                    // (kept: the cold start's key set is the same size; run_write releases it)
@@ -1400,7 +1478,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         // (with a hint table the folding kernel finishes most far hits itself and counts (tile, key) ENTRIES, one in 256: a
         //  hot far key is one entry per tile, not thousands of ops -- the bar is lower by that much)
         m->clustered_quiet = (uint64_t)c.n_long_ops * (m->d_hints ? 4096 : 256) < n ? m->clustered_quiet + 1 : 0;
-        if (m->clustered_quiet >= 8) m->clustered = false;
+        if (m->clustered_quiet >= 8) { m->clustered = false; clustered_sync(m, s); }
       }
       if (nd_chain0 == 0) { structure_stable = true; break; }  // round 0 deferred nothing: the rest of the chain ran empty
       cur_n = nd_chain0;
@@ -1429,7 +1507,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // clustered: percents of a batch needed the wave-cooperative probe (dense ids: 4-5 %; any large table at load 1/2 has a few
     // sequences beyond the budget -- the first batches of the scrambled stream do -- and must not switch it on)
     if (!m->clustered_forced && !m->clustered && (uint64_t)m->h_ctl->n_long_ops * 64 >= n) { m->clustered = true; m->clustered_quiet = 0; }
-    if (m->clustered) ensure_hints(m, s);
+    clustered_sync(m, s);
 
     const bool progress = nd < cur_n || m->h_ctl->n_long || m->h_ctl->n_tasks || m->h_ctl->n_rebal || m->h_ctl->dir_full ||
                           m->dir_used != rows_before || (uint64_t)m->dir_used * 2 >= m->dir_size;
@@ -1578,6 +1656,7 @@ void cache_sync(Matrix* m, bool drop) {
   run_write(m, OP_SET, (uint32_t)k, m->sx.p, m->sy.p, m->sv.p, m->so.p, s);   // synchronises (set resolves duplicates last)
   m->in_cache_sync = false;
   m->spec_ready = k_ready; m->expect_bulk = k_bulk; m->long_probes = k_long; m->clustered = k_clu;
+  clustered_sync(m, s);
   m->spec_nd_prev = k_nd; m->spec_nt_prev = k_nt; m->clustered_quiet = k_quiet; m->spec_gu_prev = k_gu;
   memcpy(m->spec_nk_prev, k_nk, sizeof k_nk);
   m->st.batches = batches;                                                     // bookkeeping of the caller's batches only
@@ -1639,14 +1718,30 @@ int smatrix_flush(smatrix_t* self) {
   set_device(m);
   // (like the background flusher: callers of other threads are held up only while the rows are snapshot on the device, not
   //  while they are written; the call itself returns when everything that was dirty at its start is in the file)
-  for (bool more = true; more;) {
-    std::unique_lock<std::mutex> g(m->mu);
-    more = false;
-    if (m->dirty.exchange(false)) {
-      cache_sync(m, false);
-      std::lock_guard<std::mutex> fg(m->file_mu);
-      more = file_flush(self, m, false, &g);
-      if (more) m->dirty = true;
+  // A BARRIER also against a flush that is in flight: the background flusher takes `dirty`, snapshots the rows,
+  // drops the matrix lock and writes under file_mu alone -- a call that arrives during that write finds nothing dirty, yet the
+  // rows are not in the file and their CMAP entries not published.  So every turn first waits for file_mu WITHOUT the matrix
+  // lock (no caller is held up behind us meanwhile), and the call only returns after a turn in which it either ran a complete
+  // flush itself or found nothing dirty once the flush in flight had ended.
+  for (;;) {
+    { std::lock_guard<std::mutex> wait_for_flush_in_flight(m->file_mu); }
+    bool did = false, more = false;
+    {
+      std::unique_lock<std::mutex> g(m->mu);
+      if (m->dirty.exchange(false)) {
+        did = true;
+        cache_sync(m, false);
+        std::lock_guard<std::mutex> fg(m->file_mu);
+        more = file_flush(self, m, false, &g);
+        if (more) m->dirty = true;
+      }
+    }
+    if (did && !more) break;                     // everything dirty when this turn began has been written by it
+    if (!did) {
+      // nothing was dirty: either there was nothing to do, or a flush that started before this turn took the flag -- it holds
+      // file_mu until its rows are published (and raises `dirty` again if it left rows behind)
+      { std::lock_guard<std::mutex> wait_for_flush_in_flight(m->file_mu); }
+      if (!m->dirty.load()) break;
     }
   }
   return 0;
@@ -1718,14 +1813,11 @@ smatrix_t* smatrix_open(const char* fname) {
   m->map_new.need((size_t)1 << 21);
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, c < 12 ? 1u << 18 : 1u << 12, m->stream);
   {
-    // the device's stream-ordered pool (DevBuf::need_on: scratch of one batch): freed memory stays in it up to 1 GB instead of
-    // going back to the driver at the next synchronisation, and its first use -- 8 ms to set the pool up -- happens here
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-      uint64_t keep = 1ull << 30;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    // the library's stream-ordered pool (scratch_pool; DevBuf::need_on: scratch of one batch): its first use -- 8 ms to set a
+    // pool up -- happens here
+    if (hipMemPool_t pool = scratch_pool()) {
       void* warm = nullptr;
-      if (hipMallocAsync(&warm, 4096, m->stream) == hipSuccess) (void)hipFreeAsync(warm, m->stream);
+      if (hipMallocFromPoolAsync(&warm, 4096, pool, m->stream) == hipSuccess) (void)hipFreeAsync(warm, m->stream);
     }
     (void)hipGetLastError();
   }
@@ -1733,6 +1825,13 @@ smatrix_t* smatrix_open(const char* fname) {
   ctl_push_persistent(m, m->stream);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
+  if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
+  if (const char* a = getenv("SMATRIX_REST_DBG")) {
+    m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
+    dev_malloc(&m->rest_dbg, 128);
+    HIP_OK(hipMemset(m->rest_dbg, 0, 128));
+  }
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
   m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -1744,7 +1843,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_CLUSTERED")) { m->clustered = *a != '0'; m->clustered_forced = true; }
   if (const char* a = getenv("SMATRIX_WPO_MAX")) m->wpo_max = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_HINT_LG")) m->hint_lg = std::min(28u, (uint32_t)strtoul(a, nullptr, 10));
-  if (m->clustered) ensure_hints(m, m->stream);
+  clustered_sync(m, m->stream);
   if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
@@ -1765,6 +1864,7 @@ smatrix_t* smatrix_open(const char* fname) {
       smatrix_close(self);
       return nullptr;
     }
+    if (m->clustered) { m->home_on = false; clustered_sync(m, m->stream); }     // (the loaded rows' at-home bitmaps)
     if (m->flush_ms) m->flusher = std::thread(flusher_main, self, m);
   }
   refresh_public(self);
@@ -1777,6 +1877,13 @@ void smatrix_close(smatrix_t* self) {
   Matrix* m = M(self);
   if (m) {
     set_device(m);
+    if (m->rest_dbg) {
+      unsigned long long c[16];
+      HIP_OK(hipMemcpy(c, m->rest_dbg, 128, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[smatrix] k_grow_rest_lds: steps %llu rounds %llu | most steps of a wave %llu, most rounds %llu | trips %llu, most of a wave %llu | per round: losers %.2f blocked %.2f committed %.2f\n",
+              c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
+      (void)hipFree(m->rest_dbg);
+    }
     if (m->flusher.joinable()) {                       // (it may be inside a flush: close waits for it, then does the last one)
       { std::lock_guard<std::mutex> l(m->fl_mu); m->fl_stop = true; }
       m->fl_cv.notify_all();

@@ -1,98 +1,156 @@
 #!/usr/bin/env python3
-"""Long randomized differential run of the HIP library against the oracle (not collected by pytest; run by
-hand on a GPU box: python tests/soak.py [batches] [seed]).  Random batch sizes and op kinds over Zipf and
-uniform key mixes, y = 0 and value 0 included, periodic full-state comparison (row sizes, used counters,
-cell contents), a file close/reopen in the middle."""
+"""Randomized differential run of the HIP library against the oracle: random batch sizes and op kinds over Zipf, uniform
+and dense key mixes, value 0 included, periodic full-state comparison (row sizes, used counters, cell contents, getrow), a
+file close/reopen in the middle, scalar calls on mirrored cells, flushes.
+
+By hand on a GPU box:   python tests/soak.py [batches] [seed]      (long runs, sizes up to 1.5 M ops per batch)
+Under pytest -m gpu:    tests/test_gpu_round5.py::test_bounded_soak calls run() with small batches, the forced-path switches of
+                        the write path set through the environment, and the quirk episode below.
+
+y = 0 never appears in the RANDOM batches: which slot a (0, v) entry takes depends on the order inside a batch (quirk Q1,
+src/smatrix.c:297-303), and once such an entry returns to 0 the reference's answers depend on that layout -- two legal
+serialisations of one batch then differ.  The quirk is exercised by `quirk_episode`: one op per call on a row of its own,
+where every layout is the reference's."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 import numpy as np
-from libsmatrix_amd import SparseMatrix
-from oracle import oracle as O
 
-nb = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
-path = os.path.join(tempfile.mkdtemp(prefix="smxsoak"), "s.smx")
-g, o = SparseMatrix(path), O.Oracle(path + ".ora")
+LONG_SIZES = (1, 7, 300, 5000, 60000, 400000, 1500000)
 
 
-def keys(n):
-    mode = rng.integers(0, 3)
-    if mode == 0:      # Zipf-ish over few rows and many columns: hot rows grow huge
-        x = (rng.zipf(1.3, n) % 5000).astype(np.uint32)
-        y = (rng.zipf(1.2, n) % (1 << 22)).astype(np.uint32) + 1
-    elif mode == 1:    # uniform, many rows
-        x = rng.integers(0, 300000, n, dtype=np.uint32)
-        y = rng.integers(1, 1 << 31, n, dtype=np.uint32)
-    else:              # dense ids: clustering
-        x = rng.integers(0, 2000, n, dtype=np.uint32)
-        y = rng.integers(1, 3000, n, dtype=np.uint32)
-    return x, y
+def quirk_episode(g, o, X):
+    """Quirk Q1 behind a remembered cell (tests/test_gpu_round4.py has the commented twin): a 64-cell row built one call per
+    key -- keys 1..11 and 13..30 at home, key 64 in slot 0, the row's (0, 5) entry in slot 12, key 128 walks from slot 0 to
+    slot 31 --, the far key is read twice (a clustered matrix remembers its cell), column 0 returns to 0, and the next incr of
+    key 128 must create the twin in slot 12 like the reference (answer 1, not 4).  One-op BATCHES: the lane-per-op kernels."""
+    def one(m, op, y, v=1):
+        return int(m.apply(op, np.array([X], np.uint32), np.array([y], np.uint32), np.array([v], np.uint32))[0])
+    for k in list(range(1, 12)) + list(range(13, 31)):
+        assert one(g, 2, k) == one(o, 2, k) == 1
+    assert g.row_info(X) == o.row_info(X)
+    assert one(g, 2, 64, 7) == one(o, 2, 64, 7)
+    assert one(g, 2, 0, 5) == one(o, 2, 0, 5)
+    assert one(g, 2, 128, 3) == one(o, 2, 128, 3)
+    assert (np.asarray(g.row_slots(X)) == np.asarray(o.row_slots(X))).all()
+    for _ in range(2):
+        assert one(g, 0, 128) == one(o, 0, 128)
+    assert one(g, 3, 0, 5) == one(o, 3, 0, 5) == 0
+    a, b = one(g, 2, 128, 1), one(o, 2, 128, 1)
+    assert a == b, ("the twin of quirk Q1 behind a remembered cell", a, b)
+    assert one(g, 0, 128) == one(o, 0, 128)
+    assert (np.asarray(g.row_slots(X)) == np.asarray(o.row_slots(X))).all()
 
 
-def compare(tag):
-    rows = o.list_rows()
-    got = g.rowlen_batch(rows)
-    want = np.array([o.rowlen(int(r)) for r in rows], np.uint32)
-    assert (got == want).all(), tag + ": rowlen"
-    assert g.stats()["rows"] == rows.size, tag + ": row count"
-    pick = rows[rng.integers(0, rows.size, min(rows.size, 300))]
-    for r in pick.tolist():
-        assert g.row_info(r) == o.row_info(r), (tag, r)
-        a = np.asarray(g.row_slots(r)); b = np.asarray(o.row_slots(r))
-        ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
-        ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
-        assert ka.shape == kb.shape and (ka == kb).all(), (tag, r, "cells")
-        ne = a[(a[:, 0] != 0) | (a[:, 1] != 0)]                  # getrow: the non-empty cells in slot order (big rows: segments)
-        got_row = np.asarray(g.getrow_raw(r, (g.getRowLength(r) + 1) * 8))
-        assert got_row.shape == ne.shape and (got_row == ne).all(), (tag, r, "getrow")
+def run(nb=150, seed=1, sizes=LONG_SIZES, episode=False, sample_rows=300, verbose=True):
+    from tests.gpu_adapter import GpuMatrix
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    path = os.path.join(tempfile.mkdtemp(prefix="smxsoak"), "s.smx")
+    g, o = GpuMatrix(path), O.Oracle(path + ".ora")
+
+    def keys(n):
+        mode = rng.integers(0, 4)
+        if mode == 0:      # Zipf-ish over few rows and many columns: hot rows grow huge
+            x = (rng.zipf(1.3, n) % 5000).astype(np.uint32)
+            y = (rng.zipf(1.2, n) % (1 << 22)).astype(np.uint32) + 1
+        elif mode == 1:    # uniform, many rows
+            x = rng.integers(0, 300000, n, dtype=np.uint32)
+            y = rng.integers(1, 1 << 31, n, dtype=np.uint32)
+        elif mode == 2:    # dense ids: clustering
+            x = rng.integers(0, 2000, n, dtype=np.uint32)
+            y = rng.integers(1, 3000, n, dtype=np.uint32)
+        else:              # dense Zipf ranks on a handful of rows: long runs of cells at home, keys that wrap onto them (round 5)
+            x = rng.integers(0, 12, n, dtype=np.uint32)
+            y = (rng.zipf(1.1, n) % 400000).astype(np.uint32) + 1
+        return x, y
+
+    def compare(tag):
+        rows = o.list_rows()
+        got = g.m.rowlen_batch(rows)
+        want = np.array([o.rowlen(int(r)) for r in rows], np.uint32)
+        assert (got == want).all(), tag + ": rowlen"
+        assert g.stats()["rows"] == rows.size, tag + ": row count"
+        pick = rows[rng.integers(0, rows.size, min(rows.size, sample_rows))]
+        for r in pick.tolist() + list(range(12)):
+            if o.row_info(r) is None and g.row_info(r) is None:
+                continue
+            assert g.row_info(r) == o.row_info(r), (tag, r)
+            a = np.asarray(g.row_slots(r)); b = np.asarray(o.row_slots(r))
+            ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
+            ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
+            assert ka.shape == kb.shape and (ka == kb).all(), (tag, r, "cells")
+            # every key sits where a probe from its home finds it: no empty cell in between (the reference's invariant)
+            ne = (a[:, 0] != 0) | (a[:, 1] != 0)
+            size = a.shape[0]
+            pos = np.flatnonzero(ne)
+            home = a[pos, 0].astype(np.int64) & (size - 1)
+            empties = np.flatnonzero(~ne)
+            if empties.size and pos.size:
+                dist = (pos - home) % size
+                nxt = empties[np.searchsorted(empties, home) % empties.size]          # first empty cell at/after home (cyclically)
+                gap = (nxt - home) % size
+                assert (gap > dist).all(), (tag, r, "an empty cell inside a probe sequence")
+            got_row = np.asarray(g.m.getrow_raw(r, (g.m.getRowLength(r) + 1) * 8))
+            assert got_row.shape == a[ne].shape and (got_row == a[ne]).all(), (tag, r, "getrow")
+
+    ops = 0
+    for b in range(nb):
+        n = int(rng.choice(sizes))
+        x, y = keys(n)
+        # no decr before the reopen: a cell whose value is 0 at close is DROPPED by the reference's loader
+        # (quirk Q4, src/smatrix.c:533-540) and cuts its probe chain -- which keys that hides depends on the
+        # table layout, and batch layouts legitimately differ between implementations
+        kind = int(rng.choice([2, 2, 2, 3, 1, 0] if b > nb // 2 else [2, 2, 2, 1, 0]))
+        v = rng.integers(1, 5, n, dtype=np.uint32)
+        if kind == 1:
+            # a set batch resolves duplicates highest-index-wins; feed the oracle the same final values
+            a = g.m.apply_batch(1, x, y, v); o.apply(1, x, y, v)
+            assert (a == v).all()
+        elif kind in (2, 3) and b % 3 == 1:
+            # no result array: the kernels' results-free forms (column-0 cells by 64-bit add); state checked by the gets below
+            g.m.apply_batch(kind, x, y, v, results=False); o.apply(kind, x, y, v)
+        else:
+            a = g.m.apply_batch(kind, x, y, v); bb = o.apply(kind, x, y, v)
+            if kind == 0:
+                assert (a == bb).all(), "get batch %d" % b
+            else:
+                kk = x.astype(np.uint64) << np.uint64(32) | y
+                assert (a[np.lexsort((a, kk))] == bb[np.lexsort((bb, kk))]).all(), "per-key returns, batch %d kind %d n %d" % (b, kind, n)
+        ops += n
+        if b % 7 == 3:
+            # scalar calls on cells just written (they enter the host-side mirror), left dirty across the next batch call
+            for k in range(min(n, 40)):
+                assert g.incr(int(x[k]), int(y[k]), 2) == o.incr(int(x[k]), int(y[k]), 2), "scalar incr"
+                assert g.get(int(x[k]), int(y[k])) == o.get(int(x[k]), int(y[k])), "scalar get"
+        if b % 11 == 5 and b < nb // 2:
+            g.m.flush()                                              # incremental write-out of the dirty rows (checked at the reopen)
+        chk = g.m.get_batch(x, y)
+        assert (chk == o.apply(0, x, y)).all(), "post-batch gets, batch %d kind %d n %d" % (b, kind, n)
+        if b % 10 == 9:
+            compare("batch %d" % b)
+        if b == nb // 2:
+            g.close(); o.close()
+            g, o = GpuMatrix(path), O.Oracle(path + ".ora")          # each reloads its own file
+            compare("after reopen")
+            g2 = GpuMatrix(path + ".ora")                            # and they read each other's files identically
+            assert (g2.m.get_batch(x, y) == o.apply(0, x, y)).all(), "GPU reading the oracle's file"
+            g2.close()
+        if episode and b == (2 * nb) // 3:
+            quirk_episode(g, o, 3000000 + seed)
+    compare("end")
+    st = g.stats()
+    line = ("SOAK_OK batches=%d ops=%d rows=%d rounds=%d grown=%d bulk_rounds=%d bulk_ops=%d long_probe_rounds=%d clustered=%d spec_chains=%d "
+            "spec_refused=%d cold_starts=%d mirror_hits=%d flushes=%d" %
+            (nb, ops, st["rows"], st["rounds"], st["rows_grown"], st["bulk_rounds"], st["bulk_ops"], st["long_probe_rounds"], st["clustered_mode"],
+             st["spec_chains"], st["spec_refused"], st["cold_starts"], st["scalar_cache_hits"], st["file_flushes"]))
+    if verbose:
+        print(line)
+    g.close(); o.close()
+    return st
 
 
-ops = 0
-for b in range(nb):
-    n = int(rng.choice([1, 7, 300, 5000, 60000, 400000, 1500000]))
-    x, y = keys(n)
-    # no decr before the reopen: a cell whose value is 0 at close is DROPPED by the reference's loader
-    # (quirk Q4, src/smatrix.c:533-540) and cuts its probe chain -- which keys that hides depends on the
-    # table layout, and batch layouts legitimately differ between implementations
-    kind = int(rng.choice([2, 2, 2, 3, 1, 0] if b > nb // 2 else [2, 2, 2, 1, 0]))
-    v = rng.integers(1, 5, n, dtype=np.uint32)
-    if kind == 1:
-        # a set batch resolves duplicates highest-index-wins; feed the oracle the same final values
-        a = g.apply_batch(1, x, y, v); bb = o.apply(1, x, y, v)
-        assert (a == v).all()
-    elif kind in (2, 3) and b % 3 == 1:
-        # no result array: the kernels' results-free forms (column-0 cells by 64-bit add); state checked by the gets below
-        g.apply_batch(kind, x, y, v, results=False); o.apply(kind, x, y, v)
-    else:
-        a = g.apply_batch(kind, x, y, v); bb = o.apply(kind, x, y, v)
-        if kind == 0:
-            assert (a == bb).all(), "get batch %d" % b
-    ops += n
-    if b % 7 == 3:
-        # scalar calls on cells just written (they enter the host-side mirror), left dirty across the next batch call
-        for k in range(min(n, 40)):
-            assert g.incr(int(x[k]), int(y[k]), 2) == o.incr(int(x[k]), int(y[k]), 2), "scalar incr"
-            assert g.get(int(x[k]), int(y[k])) == o.get(int(x[k]), int(y[k])), "scalar get"
-    if b % 11 == 5 and b < nb // 2:
-        g.flush()                                                # incremental write-out of the dirty rows (checked at the reopen)
-    chk = g.get_batch(x, y)
-    assert (chk == o.apply(0, x, y)).all(), "post-batch gets, batch %d kind %d n %d" % (b, kind, n)
-    if b % 10 == 9:
-        compare("batch %d" % b)
-    if b == nb // 2:
-        g.close(); o.close()
-        g, o = SparseMatrix(path), O.Oracle(path + ".ora")       # each reloads its own file
-        compare("after reopen")
-        # and they read each other's files identically
-        x2, y2 = keys(20000)
-        g2 = SparseMatrix(path + ".ora")
-        assert (g2.get_batch(x, y) == o.apply(0, x, y)).all(), "GPU reading the oracle's file"
-        g2.close()
-compare("end")
-st = g.stats()
-print("SOAK_OK batches=%d ops=%d rows=%d rounds=%d grown=%d bulk_rounds=%d bulk_ops=%d long_probe_rounds=%d mirror_hits=%d flushes=%d" %
-      (nb, ops, st["rows"], st["rounds"], st["rows_grown"], st["bulk_rounds"], st["bulk_ops"], st["long_probe_rounds"],
-       st["scalar_cache_hits"], st["file_flushes"]))
-g.close(); o.close()
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+        episode=os.environ.get("SMATRIX_CLUSTERED") == "1")
