@@ -135,6 +135,8 @@ struct Ctl {
   uint64_t spec_gu0;     //   units the growths took
   uint32_t spec_nrebal0, spec_dirfull0;
   uint32_t spec_nkind0[4];
+  // ---- the far join (k_home_list / k_far_plan): rows of >= 2^HOME_LG cells and their 1024-cell units, as of the last batch that ran it
+  uint32_t n_big, n_units;
 };
 constexpr size_t CTL_ROUND_BYTES = 64;    // one aligned fill
 static_assert(offsetof(Ctl, dir_used) == CTL_ROUND_BYTES, "the per-round part of Ctl is what ctl_reset_round zeroes");
@@ -322,6 +324,13 @@ struct ArenaHead {
   uint32_t twins;
   // the at-home bitmaps (HOME_LG) are kept up to date by the inserting kernels: probes may use them (clustered matrices)
   uint32_t home_on;
+  // the far join of a clustered write batch (see "far join" below): valid only while far_on is set -- between the scan that
+  // filled the table and the first structure change of the batch
+  uint32_t far_on;
+  uint32_t far_mask;                          // entries - 1 of the table
+  uint4* far_tab;                             // {key lo = y, key hi = row block, slot, -}
+  const unsigned long long* far_occ;          // occupancy words of the indexed rows, 16 per unit of 1024 cells
+  unsigned long long* dbg;                    // measurement runs only (SMATRIX_REST_DBG): event counters, see smatrix_close
 };
 static_assert(sizeof(ArenaHead) <= 128, "unit 0 of the arena");
 constexpr uint32_t HINT_BUDGET = 8;        // cells a lane probes before it asks for a hint, when the matrix has a hint table
@@ -344,6 +353,63 @@ __device__ inline void hint_put(const uint8_t* arena, const uint64_t* cells, uin
   if (hmask == 0 || Y == 0) return;
   const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
   ah->hints[hint_index(base, Y, hmask)] = uint4{Y, base, pos, 0u};
+}
+
+// ---- the far join of a clustered write batch (round 5) -------------------------------------------------------------------------
+// Dense ids leave a write batch with 2-4 x 10^5 ops whose probe outruns the lane's budget: keys that wrap onto a run of cells
+// at home.  Walking each of them to its end -- even a wave per op, even stepping over at-home cells by the bitmaps -- costs
+// 10^9 cells per batch (4.5-5.4 ms), most of it to learn that a NEW key is absent; prep then walks the deferred ones again.
+// But all big rows together are only ~45 M cells.  So, per batch, on the quiescent tables between the folding kernel and the
+// wave-per-op pass:
+//   1. k_far_keys   the far keys of the deferred list enter a hash table F keyed {row block, y}            (~2 x 10^5 keys)
+//   2. k_far_scan   ONE streaming pass over every row of >= 2^HOME_LG cells: each displaced cell looks its key up in F and
+//                   leaves its slot there; the pass also writes an OCCUPANCY word per 64 cells into a scratch bitmap
+//   3. the wave-per-op pass and prep ask F: slot known -> the op goes straight to its cell; key in F without a slot -> it was
+//      ABSENT when the tables were scanned, so the probe goes on by the occupancy bitmap: a cell that was taken at the scan
+//      holds another key (keys never leave their cells), only cells that were empty then are looked at -- they are empty, or
+//      hold a key inserted since, possibly this very one.
+// Nothing persists: the table and the bitmap are rebuilt from the tables themselves in every batch and dropped (far_on = 0)
+// before the first row doubles, so there is no staleness to reason about; a row or key that did not fit (capacities are
+// estimates from the batch before) is simply not in F and takes the wave-cooperative walk as before.  Off once a probe chain
+// may have been cut (ArenaHead::twins: a key may then sit twice and the scan cannot know which cell a probe finds first).
+constexpr uint32_t FAR_UNIT_LG = 10;                      // rows are scanned in units of 1024 cells
+constexpr uint32_t FAR_NOT_FOUND = 0xFFFFFFFFu;
+__device__ inline uint32_t far_hash(uint32_t base, uint32_t Y) { return fmix32(base * 0x9E3779B1u + Y * 0x85EBCA77u + 0x27d4eb2fu); }
+// the entry of {base, Y}, or nullptr (linear probing; a never-used entry ends the search)
+__device__ inline uint4* far_entry(uint4* tab, uint32_t tmask, uint32_t base, uint32_t Y) {
+  uint32_t e = far_hash(base, Y) & tmask;
+  for (uint32_t guard = 0; guard <= tmask; guard++) {
+    const uint2 k = *reinterpret_cast<const uint2*>(&tab[e]);
+    if (k.x == Y && k.y == base) return &tab[e];
+    if (k.x == 0 && k.y == 0) return nullptr;
+    e = (e + 1) & tmask;
+  }
+  return nullptr;
+}
+// insert {base, Y} (slot not known yet); false when the table is too crowded around its home
+__device__ inline bool far_insert(uint4* tab, uint32_t tmask, uint32_t base, uint32_t Y, uint32_t slot) {
+  const unsigned long long key = ((unsigned long long)base << 32) | Y;
+  uint32_t e = far_hash(base, Y) & tmask;
+  for (uint32_t guard = 0; guard < 64; guard++) {
+    unsigned long long prev = *reinterpret_cast<const unsigned long long*>(&tab[e]);
+    if (prev == 0ull) prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[e]), 0ull, key);
+    if (prev == 0ull || prev == key) { if (prev == 0ull || slot != FAR_NOT_FOUND) tab[e].z = slot; return true; }
+    e = (e + 1) & tmask;
+  }
+  return false;
+}
+enum { FAR_NONE = 0, FAR_FOUND = 1, FAR_ABSENT = 2 };
+struct FarHit { uint32_t state, slot; const unsigned long long* occ; };
+// what the join knows about key Y of the table at `cells` (ArenaHead::far_on must have been checked)
+__device__ inline FarHit far_find(const uint8_t* arena, const uint64_t* cells, uint32_t Y) {
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
+  const uint4* row = far_entry(ah->far_tab, ah->far_mask, base, 0u);          // the row's entry: its first unit
+  if (!row || Y == 0) return FarHit{FAR_NONE, 0u, nullptr};
+  const uint4* e = far_entry(ah->far_tab, ah->far_mask, base, Y);
+  if (!e) return FarHit{FAR_NONE, 0u, nullptr};
+  if (e->z != FAR_NOT_FOUND) return FarHit{FAR_FOUND, e->z, nullptr};
+  return FarHit{FAR_ABSENT, 0u, ah->far_occ + (size_t)row->z * 16u};
 }
 
 struct LongProbe {
@@ -383,7 +449,10 @@ __device__ inline uint32_t select_bit(unsigned long long w, uint32_t r) {
 // examined 64 at a time in probe order: lane i finds the owner of candidate i by a binary search over the prefix sums
 // (six shuffles) and its bit by a select in the owner's word.  A dense run costs one mask load per 4096 cells; a pile of
 // displaced cells costs what it cost before.
-__device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t mask, uint32_t Y, uint32_t pos, bool use_home = false) {
+// occ (per lane; the far join): the key was ABSENT when the row's occupancy words were written -- the whole probe goes by those
+// words (a set bit: the cell was taken then, by another key), from `pos` on.
+__device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t mask, uint32_t Y, uint32_t pos, bool use_home = false,
+                                      const unsigned long long* occ = nullptr) {
   const uint32_t lane = __lane_id();
   uint64_t todo = __ballot(need);
   uint32_t result = PROBE_NONE;
@@ -394,8 +463,11 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
         ((uint64_t)(uint32_t)__shfl((int)((uint64_t)cells >> 32), src) << 32) | (uint32_t)__shfl((int)(uint64_t)cells, src));
     const uint32_t mb = (uint32_t)__shfl((int)mask, src), yb = (uint32_t)__shfl((int)Y, src), pb = (uint32_t)__shfl((int)pos, src);
     uint32_t found = PROBE_NONE;
-    const bool by_bits = use_home && mb + 1u >= (1u << HOME_LG);           // (wave-uniform)
-    for (uint64_t done = 0; done <= mb && found == PROBE_NONE; done += 256) {          // wave-uniform
+    const unsigned long long* ob = reinterpret_cast<const unsigned long long*>(
+        ((uint64_t)(uint32_t)__shfl((int)((uint64_t)occ >> 32), src) << 32) | (uint32_t)__shfl((int)(uint64_t)occ, src));
+    const bool by_occ = ob != nullptr;                                       // (wave-uniform)
+    const bool by_bits = by_occ || (use_home && mb + 1u >= (1u << HOME_LG));
+    for (uint64_t done = 0; !by_occ && done <= mb && found == PROBE_NONE; done += 256) {          // wave-uniform
       uint64_t c[4];
       bool ok[4];
 #pragma unroll
@@ -412,9 +484,9 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
       if (by_bits) break;                                                    // the rest of the walk goes by the bitmap
     }
     if (by_bits && found == PROBE_NONE) {
-      const unsigned long long* hb = cells_home(cb, mb);
+      const unsigned long long* hb = by_occ ? ob : cells_home(cb, mb);
       const uint32_t nwords = (mb + 1u) >> 6, wmask = nwords - 1u;
-      const uint32_t start = (pb + 256u) & mb;                             // cells [pb, pb + 256) have been looked at
+      const uint32_t start = by_occ ? pb : (pb + 256u) & mb;               // (cells [pb, pb + 256) have been looked at)
       const uint32_t w0 = start >> 6;
       // one full turn: the words w0 .. w0 + nwords (the first one from bit start & 63 on, and once more whole at the end)
       for (uint32_t wd = 0; wd <= nwords && found == PROBE_NONE; wd += 64) {        // wave-uniform
@@ -663,8 +735,24 @@ __device__ __forceinline__ void apply_body(
       }
     }
     uint32_t p_coop = PROBE_NONE;                           // where the wave-cooperative probe ended
+    // the far join of this batch (the wave-per-op pass in front of prep): the key's cell is known, or the key is known to have
+    // been absent when the tables were scanned and the probe goes by the occupancy words
+    const unsigned long long* occ = nullptr;
+    if (WPO && HM == 2 && lp.need) {
+      const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+      if (ah->far_on && !ah->twins) {
+        const FarHit fh = far_find(arena, lp.cells, Y);
+        if (ah->dbg) atomicAdd(&ah->dbg[16 + fh.state], 1ull);
+        if (fh.state == FAR_FOUND) {
+          if (has_hints) was_long = ((fh.slot - Y) & lp.mask) > PROBE_BUDGET;
+          lp.need = false;
+          r = apply_row<OP, true, 1>(d, s, arena, Y, V, fh.slot, &deferred, &lp);
+          p_coop = fh.slot;
+        } else if (fh.state == FAR_ABSENT) occ = fh.occ;
+      }
+    }
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
-      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home);
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home, occ);
       if (lp.need) {
         lp.need = false;
         if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; was_long = true; }   // neither the key nor an empty cell: prep grows the row
@@ -1293,7 +1381,10 @@ __device__ __forceinline__ void prep_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl, uint32_t st, uint32_t create_only) {
+    FreeLists fl, uint32_t st, uint32_t create_only, uint32_t wpo_max) {
+  // wpo_max (clustered matrices): a list of at most so many ops is taken a WAVE per op -- lane 0 holds the op, the wave finishes
+  //             its long probe -- like k_apply_wpo: a few hundred deferred ops of big clustered rows, 64 to a wave, walked their
+  //             10^4..10^5 cells one lane after the other (7-16 ms for 300-700 ops of the dense-id stream's late rounds)
   // create_only bit 0: rows are created, nothing is flagged for growth (the bulk path decides growth itself, k_fix_rows)
   //             bit 1: the listed ops' keys are known to be ABSENT (k_insert_keys has just looked: a key that exists is never
   //                    deferred, and nobody inserts another list entry's key) -- step C's probe is skipped
@@ -1305,10 +1396,12 @@ __device__ __forceinline__ void prep_body(
   __shared__ unsigned long long l_units;
   const uint32_t n = aload(&ctl->n_defer);
   const uint64_t stride = (uint64_t)g.nb * blockDim.x;
-  for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n; t064 += stride) {             // block-uniform trip count (64-bit: no wrap near 2^32)
-    const uint32_t t0 = (uint32_t)t064;
-    const uint32_t t = t0 + threadIdx.x;
-    const bool live = t < n;
+  const bool wpo = n <= wpo_max;
+  const uint64_t n_lanes = wpo ? (uint64_t)n * 64u : (uint64_t)n;
+  for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n_lanes; t064 += stride) {       // block-uniform trip count (64-bit: no wrap near 2^32)
+    const uint64_t tl = t064 + threadIdx.x;
+    const uint32_t t = wpo ? (uint32_t)(tl >> 6) : (uint32_t)tl;
+    const bool live = tl < n_lanes && (!wpo || (tl & 63u) == 0);
     uint32_t X = 0, Y = 0;
     if (live) {
       const uint32_t j = defer ? defer[t] : t;         // (no list: the ops are the n_defer entries of xs / ys themselves -- packed keys)
@@ -1451,8 +1544,18 @@ __device__ __forceinline__ void prep_body(
         }
       }
     }
+    // (the far join of this batch, while it is valid: the key's cell is known, or the rest of the probe goes by the occupancy words)
+    const unsigned long long* occ = nullptr;
+    {
+      const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+      if (lp.need && ah->far_on && !ah->twins) {
+        const FarHit fh = far_find(arena, lp.cells, Y);
+        if (fh.state == FAR_FOUND && cell_key(lp.cells[fh.slot]) == Y) { absent = false; lp.need = false; }
+        else if (fh.state == FAR_ABSENT) occ = fh.occ;
+      }
+    }
     while (__any(lp.need)) {                        // long sequences (dense ids): the wave finishes them (coop_probe)
-      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, reinterpret_cast<const ArenaHead*>(arena)->home_on != 0);
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, reinterpret_cast<const ArenaHead*>(arena)->home_on != 0, occ);
       if (lp.need) {
         lp.need = false;
         absent = p == PROBE_NONE || cell_key(lp.cells[p]) != Y;     // the table is quiescent here: the answer is final
@@ -1530,8 +1633,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl, uint32_t st, uint32_t create_only) {
-  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st, create_only);
+    FreeLists fl, uint32_t st, uint32_t create_only, uint32_t wpo_max) {
+  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st, create_only, wpo_max);
 }
 
 // ---- the bulk path: many deferred ops (bulk loads, the first batches of a matrix) ---------------------------
@@ -3125,6 +3228,93 @@ __global__ __launch_bounds__(256) void k_home_rebuild(const DirSlot* dir, const 
     const uint64_t c = cells[p];
     const uint64_t m = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & mask) == p);
     if (lane == 0) hb[w] = m;
+  }
+}
+
+// ---- the far join's kernels (see "far join" above) ---------------------------------------------------------------------------
+// k_far_plan (one workgroup): the listed big rows (k_home_list) get their units -- an exclusive scan of 2^(lg - FAR_UNIT_LG) --,
+// the unit -> row map, and their entry {row block, 0} -> first unit in F.  Rows that do not fit the capacities are left out.
+__global__ __launch_bounds__(1024) void k_far_plan(Ctl* ctl, const DirSlot* dir, const uint32_t* list, uint32_t cap_rows, uint32_t* unit_first,
+                                                   uint32_t* unit_row, uint32_t cap_units, uint4* tab, uint32_t tmask) {
+  __shared__ uint32_t l_sum[1024];
+  const uint32_t n = min(aload(&ctl->n_big), cap_rows), tid = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u, i0 = min(n, tid * per), i1 = min(n, i0 + per);
+  uint32_t mine = 0;
+  for (uint32_t i = i0; i < i1; i++) mine += 1u << (meta_lg(dir[list[i]].meta) - FAR_UNIT_LG);
+  l_sum[tid] = mine;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {                           // inclusive scan
+    const uint32_t v = tid >= d ? l_sum[tid - d] : 0u;
+    __syncthreads();
+    l_sum[tid] += v;
+    __syncthreads();
+  }
+  uint32_t first = l_sum[tid] - mine;
+  for (uint32_t i = i0; i < i1; i++) {
+    const DirSlot d = dir[list[i]];
+    const uint32_t units = 1u << (meta_lg(d.meta) - FAR_UNIT_LG);
+    unit_first[i] = first;
+    for (uint32_t u = 0; u < units && first + u < cap_units; u++) unit_row[first + u] = i;
+    if (first + units <= cap_units) far_insert(tab, tmask, d.base, 0u, first);     // (a row that does not fit whole is not in F)
+    first += units;
+  }
+  if (tid == 1023) ctl->n_units = l_sum[1023];
+}
+
+// k_far_keys: the deferred ops whose probe outruns the lane's budget on a row of >= 2^HOME_LG cells (what the wave-per-op pass is
+// going to find out again: nothing changes in between) enter F.  `limit`: ops beyond it are not entered (the table would fill up).
+__global__ __launch_bounds__(256) void k_far_keys(const Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, const uint32_t* idx,
+                                                  const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t st, uint4* tab,
+                                                  uint32_t tmask, uint32_t limit) {
+  const uint32_t n = min(aload(&ctl->n_prev), limit);
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const size_t at = (size_t)idx[t] * st;
+    const uint32_t Y = ys[at];
+    uint4 s;
+    if (Y == 0 || !dir_find(dir, dmask, xs[at], &s) || s.z == 0 || meta_lg(s.x) < HOME_LG) continue;
+    const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
+    const uint64_t* cells = row_cells(arena, s.z);
+    uint32_t pos = Y & mask;
+    bool far = true;
+    for (uint32_t step = 0; step <= HINT_BUDGET; step++) {
+      const uint64_t c = cells[pos];
+      if (cell_key(c) == Y || c == 0) { far = false; break; }
+      pos = (pos + 1) & mask;
+    }
+    if (far) far_insert(tab, tmask, s.z, Y, FAR_NOT_FOUND);
+  }
+}
+
+// k_far_scan: a wave per unit of 1024 cells: the occupancy words (a (0, v) cell counts as free: it may turn back into an empty
+// one, quirk Q1), and every displaced cell's slot into its key's entry of F, if it has one.
+__global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot* dir, const uint32_t* list, const uint32_t* unit_first,
+                                                  const uint32_t* unit_row, uint32_t cap_units, uint8_t* arena, uint4* tab, uint32_t tmask,
+                                                  unsigned long long* occ) {
+  const uint32_t n_units = min(aload(&ctl->n_units), cap_units);
+  const uint32_t lane = threadIdx.x & 63u, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < n_units; u += nwaves) {     // (wave-uniform)
+    const uint32_t i = unit_row[u];
+    const DirSlot d = dir[list[i]];
+    const uint32_t mask = (1u << meta_lg(d.meta)) - 1u, p0 = (u - unit_first[i]) << FAR_UNIT_LG;
+    if (unit_first[i] + ((mask + 1u) >> FAR_UNIT_LG) > cap_units) continue;           // (the row does not fit whole: not in F)
+    const uint64_t* cells = row_cells(arena, d.base) + p0;
+#pragma unroll
+    for (uint32_t q0 = 0; q0 < 16; q0 += 8) {
+      uint64_t c[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) c[q] = cells[(q0 + q) * 64u + lane];
+#pragma unroll
+      for (uint32_t q = 0; q < 8; q++) {
+        const uint32_t p = p0 + (q0 + q) * 64u + lane, key = cell_key(c[q]);
+        const bool taken = c[q] != 0 && key != 0;
+        const uint64_t m = __ballot(taken);
+        if (lane == 0) occ[(size_t)u * 16u + q0 + q] = m;
+        if (taken && (key & mask) != p) {
+          uint4* e = far_entry(tab, tmask, d.base, key);
+          if (e) e->z = p;
+        }
+      }
+    }
   }
 }
 

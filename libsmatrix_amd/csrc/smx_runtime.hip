@@ -665,6 +665,13 @@ struct Matrix {
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
+  // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
+  bool far_join = true;
+  DevBuf<uint4> far_tab;
+  DevBuf<uint32_t> far_list, far_unit_first, far_unit_row;
+  DevBuf<unsigned long long> far_occ;
+  uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
+  uint32_t far_rows_seen = 0, far_units_seen = 0;   // rows of >= 2^HOME_LG cells / their 1024-cell units when they were last counted
   bool home_on = false;                 // the rows' at-home bitmaps (smx_kernels.hpp HOME_LG) are kept up to date and used by the probes: host mirror of ArenaHead::home_on
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
   uint32_t cold_share = 64;             // ... and only when at least 1/cold_share of the batch is still pending (SMATRIX_COLD_SHARE).  (Not stricter: the
@@ -815,6 +822,40 @@ void clustered_sync(Matrix* m, hipStream_t s) {
     arena_head_set(m, offsetof(ArenaHead, home_on), 0u, s);
     m->home_on = false;
   }
+}
+
+// The far join in front of the wave-per-op pass of a clustered write batch (smx_kernels.hpp "far join"): the table and the
+// occupancy bitmap are (re)built on stream s for the deferred list `dl` (length on the device: ctl->n_prev); every capacity is an
+// estimate -- what does not fit is left out of the table and takes the old walk.  Returns false when nothing was enqueued.
+bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32_t* x, const uint32_t* y, uint32_t est_nd) {
+  if (!m->far_join || !m->home_on || m->dir_used == 0) return false;
+  const uint32_t cap_rows = (uint32_t)std::min<uint64_t>(m->dir_used, (uint64_t)m->far_rows_seen * 5 / 4 + 1024);
+  const uint32_t cap_units = (uint32_t)std::min<uint64_t>(m->arena.mapped >> (FAR_UNIT_LG + 3), (uint64_t)m->far_units_seen * 5 / 4 + 8192);
+  uint32_t lg = 16;
+  while (lg < 23 && (1ull << lg) < 4ull * est_nd + 2ull * cap_rows) lg++;
+  m->far_list.need(cap_rows); m->far_unit_first.need(cap_rows); m->far_unit_row.need(cap_units);
+  const bool moved = m->far_tab.cap < ((size_t)1 << lg) || m->far_occ.cap < (size_t)cap_units * 16;
+  m->far_tab.need((size_t)1 << lg); m->far_occ.need((size_t)cap_units * 16);
+  if (moved || m->far_tab_lg != lg) {
+    struct { uint32_t mask; uint4* tab; const unsigned long long* occ; } __attribute__((packed)) w = {(1u << lg) - 1u, m->far_tab.p, m->far_occ.p};
+    static_assert(sizeof(w) == 20 && offsetof(ArenaHead, far_tab) == offsetof(ArenaHead, far_mask) + 4 && offsetof(ArenaHead, far_occ) == offsetof(ArenaHead, far_tab) + 8, "ArenaHead layout");
+    HIP_OK(hipMemcpyAsync(m->arena.base + offsetof(ArenaHead, far_mask), &w, sizeof(w), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));                       // (`w` is on the stack; rare: the buffers moved)
+    m->far_tab_lg = lg;
+  }
+  const uint32_t tmask = (1u << lg) - 1u;
+  HIP_OK(hipMemsetAsync(m->far_tab.p, 0, (size_t)16 << lg, s));
+  HIP_OK(hipMemsetAsync(&m->d_ctl->n_big, 0, 8, s));       // n_big, n_units
+  hipLaunchKernelGGL(k_home_list, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_dir, m->dir_size, m->far_list.p, &m->d_ctl->n_big, cap_rows);
+  hipLaunchKernelGGL(k_far_plan, dim3(1), dim3(1024), 0, s, m->d_ctl, m->d_dir, m->far_list.p, cap_rows, m->far_unit_first.p, m->far_unit_row.p, cap_units,
+                     m->far_tab.p, tmask);
+  hipLaunchKernelGGL(k_far_keys, dim3(std::min<uint32_t>(blocks_for(est_nd), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, dl, x, y,
+                     m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u);
+  hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 16384)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_list.p,
+                     m->far_unit_first.p, m->far_unit_row.p, cap_units, m->arena.base, m->far_tab.p, tmask, m->far_occ.p);
+  HIP_OK(hipGetLastError());
+  arena_head_set(m, offsetof(ArenaHead, far_on), 1u, s);
+  return true;
 }
 
 template <int OP>
@@ -1241,7 +1282,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                        (uint64_t)(m->arena.mapped / UNIT_BYTES), (const uint32_t*)nullptr, reinterpret_cast<const uint32_t*>(kout) + 1,
-                       reinterpret_cast<const uint32_t*>(kout), m->tasks.p, m->klist.p, m->klist_cap, m->rebal.p, m->fl, 2u, 2u);
+                       reinterpret_cast<const uint32_t*>(kout), m->tasks.p, m->klist.p, m->klist_cap, m->rebal.p, m->fl, 2u, 2u, 0u);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     m->st.rounds++;
@@ -1390,10 +1431,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       }
     }
     const auto launch_prep = [&](const uint32_t* list) {
-      hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
+      // (a short list of a clustered matrix is taken a wave per op: the grid covers 64 lanes per op then)
+      const uint32_t pgrid = m->clustered && cur_n <= 8192u ? blocks_for((uint64_t)cur_n * 64, PREP_THREADS) : blocks_for(cur_n, PREP_THREADS);
+      hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(pgrid, m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                          m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                          (uint64_t)(m->arena.mapped / UNIT_BYTES), list, x, y, m->tasks.p, m->klist.p, m->klist_cap,
-                         m->rebal.p, m->fl, m->in_stride, 0u);
+                         m->rebal.p, m->fl, m->in_stride, 0u, m->clustered ? 8192u : 0u);
     };
     // Clustered tables (dense ids): the folding kernel sets every op aside whose probe outruns its budget -- 770 000 of a
     // 2^24-op batch of the dense stream, nearly all of them HITS on keys that sit far from home -- and prep then walked
@@ -1401,9 +1444,11 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // a wave-per-op pass first (k_apply_wpo); prep, the growth round and the retry see what that pass leaves: the ops
     // that really wait for a structure change.
     const bool pre_pass = chained && m->clustered && (op == OP_INCR || op == OP_DECR);
+    bool far_joined = false;
     if (pre_pass) {
       uint32_t* dlp = m->defer[1].p;
       hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
+      far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n));
       const dim3 wgrid(65536);
       if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
       else hipLaunchKernelGGL((k_apply_wpo<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
@@ -1412,6 +1457,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     }
     launch_prep(dl);
     HIP_OK(hipGetLastError());
+    if (far_joined) arena_head_set(m, offsetof(ArenaHead, far_on), 0u, s);     // (rows are about to double: the join's view of the tables ends here)
     DBG_STEP(m, s, "k_prep");
     uint32_t nd_chain0 = 0;
     if (chained) {
@@ -1451,6 +1497,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       // bookkeeping of the round the host did not see, then on as if round 1 had just been read back
       const Ctl& c = *m->h_ctl;
       nd_chain0 = c.spec_nd0;
+      if (far_joined) { m->far_rows_seen = c.n_big; m->far_units_seen = c.n_units; }
       if (!m->in_cache_sync) m->last_nd0 = nd_chain0;
       m->expect_bulk = (uint64_t)nd_chain0 * 8 >= n;
       m->st.spec_chains++;
@@ -1467,6 +1514,14 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         m->st.spec_refused++;
         const uint32_t zero = 0;
         HIP_OK(hipMemcpyAsync(&m->d_ctl->spec_failed, &zero, 4, hipMemcpyHostToDevice, s));
+      }
+      if (m->trace_rounds && m->rest_dbg) {
+        static thread_local unsigned long long last[3] = {0, 0, 0};
+        unsigned long long now[3];
+        HIP_OK(hipMemcpy(now, m->rest_dbg + 16, 24, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smatrix]   far join: big rows %u (%u units); long probes of the pass: not in the table %llu, cell known %llu, absent %llu\n",
+                c.n_big, c.n_units, now[0] - last[0], now[1] - last[1], now[2] - last[2]);
+        memcpy(last, now, sizeof last);
       }
       if (m->trace_rounds)
         fprintf(stderr, "[smatrix] batch %llu chain: ops=%u deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u | long probes %u%s\n",
@@ -1827,10 +1882,12 @@ smatrix_t* smatrix_open(const char* fname) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
+  if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
-    dev_malloc(&m->rest_dbg, 128);
-    HIP_OK(hipMemset(m->rest_dbg, 0, 128));
+    dev_malloc(&m->rest_dbg, 256);
+    HIP_OK(hipMemset(m->rest_dbg, 0, 256));
+    HIP_OK(hipMemcpy(m->arena.base + offsetof(ArenaHead, dbg), &m->rest_dbg, 8, hipMemcpyHostToDevice));
   }
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
@@ -1878,8 +1935,9 @@ void smatrix_close(smatrix_t* self) {
   if (m) {
     set_device(m);
     if (m->rest_dbg) {
-      unsigned long long c[16];
-      HIP_OK(hipMemcpy(c, m->rest_dbg, 128, hipMemcpyDeviceToHost));
+      unsigned long long c[32];
+      HIP_OK(hipMemcpy(c, m->rest_dbg, 256, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[smatrix] far join, long probes of the wave-per-op pass: not in the table %llu, cell known %llu, absent at the scan %llu\n", c[16], c[17], c[18]);
       fprintf(stderr, "[smatrix] k_grow_rest_lds: steps %llu rounds %llu | most steps of a wave %llu, most rounds %llu | trips %llu, most of a wave %llu | per round: losers %.2f blocked %.2f committed %.2f\n",
               c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
       (void)hipFree(m->rest_dbg);
@@ -1907,6 +1965,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_small) (void)hipHostFree(m->h_small);
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
+      m->far_tab.release(); m->far_list.release(); m->far_unit_first.release(); m->far_unit_row.release(); m->far_occ.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);

@@ -104,6 +104,8 @@ def run(nb=150, seed=1, sizes=LONG_SIZES, episode=False, sample_rows=300, verbos
         # table layout, and batch layouts legitimately differ between implementations
         kind = int(rng.choice([2, 2, 2, 3, 1, 0] if b > nb // 2 else [2, 2, 2, 1, 0]))
         v = rng.integers(1, 5, n, dtype=np.uint32)
+        if kind in (2, 3):
+            v = ((x * 3 + y) % 5 + 1).astype(np.uint32)          # one amount per key: the per-key return multisets are then order-free
         if kind == 1:
             # a set batch resolves duplicates highest-index-wins; feed the oracle the same final values
             a = g.m.apply_batch(1, x, y, v); o.apply(1, x, y, v)
