@@ -329,11 +329,16 @@ struct ArenaHead {
   uint32_t far_on;
   uint32_t far_mask;                          // entries - 1 of the table
   uint4* far_tab;                             // {key lo = y, key hi = row block, slot, -}
-  const unsigned long long* far_occ;          // occupancy words of the indexed rows, 16 per unit of 1024 cells
+  const unsigned long long* far_occ;          // occupancy words of the indexed rows, FAR_UNIT_WORDS per unit
+  const uint32_t* far_zeros;                  // free cells per unit (at the scan): a probe steps over units without any
+  uint32_t far_overflow;                      // a far key did not fit the table in this batch: no claimed inserts (k_far_keys, far_claim_insert)
   unsigned long long* dbg;                    // measurement runs only (SMATRIX_REST_DBG): event counters, see smatrix_close
 };
 static_assert(sizeof(ArenaHead) <= 128, "unit 0 of the arena");
-constexpr uint32_t HINT_BUDGET = 8;        // cells a lane probes before it asks for a hint, when the matrix has a hint table
+#ifndef SMX_HINT_BUDGET
+#define SMX_HINT_BUDGET 8
+#endif
+constexpr uint32_t HINT_BUDGET = SMX_HINT_BUDGET;        // cells a lane probes before it asks for a hint, when the matrix has a hint table
 __device__ inline uint32_t hint_index(uint32_t base, uint32_t Y, uint32_t hmask) {
   return fmix32(base * 0x9E3779B1u ^ Y * 0x85EBCA77u) & hmask;
 }
@@ -355,6 +360,24 @@ __device__ inline void hint_put(const uint8_t* arena, const uint64_t* cells, uin
   ah->hints[hint_index(base, Y, hmask)] = uint4{Y, base, pos, 0u};
 }
 
+constexpr uint32_t PROBE_NONE = 0xFFFFFFFFu;
+// the position of the r-th (0-based) set bit of w; r < popcount(w)
+__device__ inline uint32_t select_bit(unsigned long long w, uint32_t r) {
+  uint32_t pos = 0;
+  uint32_t lo = (uint32_t)w, c = __popc(lo);
+  if (r >= c) { r -= c; pos = 32; lo = (uint32_t)(w >> 32); }
+  c = __popc(lo & 0xFFFFu);
+  if (r >= c) { r -= c; pos += 16; lo >>= 16; }
+  c = __popc(lo & 0xFFu);
+  if (r >= c) { r -= c; pos += 8; lo >>= 8; }
+  c = __popc(lo & 0xFu);
+  if (r >= c) { r -= c; pos += 4; lo >>= 4; }
+  c = __popc(lo & 0x3u);
+  if (r >= c) { r -= c; pos += 2; lo >>= 2; }
+  if (r >= (lo & 1u)) pos += 1;
+  return pos;
+}
+
 // ---- the far join of a clustered write batch (round 5) -------------------------------------------------------------------------
 // Dense ids leave a write batch with 2-4 x 10^5 ops whose probe outruns the lane's budget: keys that wrap onto a run of cells
 // at home.  Walking each of them to its end -- even a wave per op, even stepping over at-home cells by the bitmaps -- costs
@@ -372,7 +395,9 @@ __device__ inline void hint_put(const uint8_t* arena, const uint64_t* cells, uin
 // before the first row doubles, so there is no staleness to reason about; a row or key that did not fit (capacities are
 // estimates from the batch before) is simply not in F and takes the wave-cooperative walk as before.  Off once a probe chain
 // may have been cut (ArenaHead::twins: a key may then sit twice and the scan cannot know which cell a probe finds first).
-constexpr uint32_t FAR_UNIT_LG = 10;                      // rows are scanned in units of 1024 cells
+constexpr uint32_t FAR_UNIT_LG = 9;                       // rows are scanned in units of 512 cells (8 occupancy words)
+constexpr uint32_t FAR_ROW_LG = 9;                        // ... from 512 cells up (long probes start in rows of a few hundred cells)
+constexpr uint32_t FAR_UNIT_WORDS = 1u << (FAR_UNIT_LG - 6);
 constexpr uint32_t FAR_NOT_FOUND = 0xFFFFFFFFu;
 __device__ inline uint32_t far_hash(uint32_t base, uint32_t Y) { return fmix32(base * 0x9E3779B1u + Y * 0x85EBCA77u + 0x27d4eb2fu); }
 // the entry of {base, Y}, or nullptr (linear probing; a never-used entry ends the search)
@@ -399,17 +424,127 @@ __device__ inline bool far_insert(uint4* tab, uint32_t tmask, uint32_t base, uin
   return false;
 }
 enum { FAR_NONE = 0, FAR_FOUND = 1, FAR_ABSENT = 2 };
-struct FarHit { uint32_t state, slot; const unsigned long long* occ; };
+struct FarHit { uint32_t state, slot; const unsigned long long* occ; uint4* entry; const uint32_t* zeros; };
 // what the join knows about key Y of the table at `cells` (ArenaHead::far_on must have been checked)
 __device__ inline FarHit far_find(const uint8_t* arena, const uint64_t* cells, uint32_t Y) {
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
   const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
-  const uint4* row = far_entry(ah->far_tab, ah->far_mask, base, 0u);          // the row's entry: its first unit
-  if (!row || Y == 0) return FarHit{FAR_NONE, 0u, nullptr};
-  const uint4* e = far_entry(ah->far_tab, ah->far_mask, base, Y);
-  if (!e) return FarHit{FAR_NONE, 0u, nullptr};
-  if (e->z != FAR_NOT_FOUND) return FarHit{FAR_FOUND, e->z, nullptr};
-  return FarHit{FAR_ABSENT, 0u, ah->far_occ + (size_t)row->z * 16u};
+  if (Y == 0) return FarHit{FAR_NONE, 0u, nullptr, nullptr, nullptr};
+  uint4* tab = ah->far_tab;
+  const uint32_t tmask = ah->far_mask;
+  // (both look-ups' first entries are asked for together: two dependent round trips less)
+  uint32_t er = far_hash(base, 0u) & tmask, ek = far_hash(base, Y) & tmask;
+  uint4 vr = tab[er], vk = tab[ek];
+  const uint4* row = nullptr;
+  uint4* e = nullptr;
+  for (uint32_t guard = 0; guard <= tmask; guard++) {
+    if (vr.x == 0u && vr.y == base) { row = &tab[er]; break; }
+    if (vr.x == 0u && vr.y == 0u) break;
+    er = (er + 1) & tmask;
+    vr = tab[er];
+  }
+  if (!row) return FarHit{FAR_NONE, 0u, nullptr, nullptr, nullptr};
+  const uint32_t first_unit = vr.z;
+  for (uint32_t guard = 0; guard <= tmask; guard++) {
+    if (vk.x == Y && vk.y == base) { e = &tab[ek]; break; }
+    if (vk.x == 0u && vk.y == 0u) break;
+    ek = (ek + 1) & tmask;
+    vk = tab[ek];
+  }
+  if (!e) return FarHit{FAR_NONE, 0u, nullptr, nullptr, nullptr};
+  if (vk.z != FAR_NOT_FOUND) return FarHit{FAR_FOUND, vk.z, nullptr, e, nullptr};
+  return FarHit{FAR_ABSENT, 0u, ah->far_occ + (size_t)first_unit * FAR_UNIT_WORDS, e, ah->far_zeros + first_unit};
+}
+// ONE LANE's probe by the occupancy words of its row (the key was absent at the scan): the first cell at/after `pos`
+// (cyclically) that was free then and is empty or holds Y now; PROBE_NONE after a full turn.  Units without a free cell are
+// stepped over by their counts, so a key that wraps onto a 60 000-cell run costs ~120 loads, not 60 000 -- and 64 lanes do
+// their walks side by side, where the wave-cooperative probe took one op's at a time.
+// bits_only: the first cell that was free at the scan, whatever it holds now (the op that inserts by rank: nobody else inserts
+// its key, so the cells that others have filled since the scan -- a hot front grows by thousands of cells during the pass, and
+// looking at them one by one was 400 us for the slowest lane of a wave -- need not be looked at).
+__device__ inline uint32_t far_walk(const uint64_t* cells, uint32_t mask, const unsigned long long* occ, const uint32_t* zeros, uint32_t Y, uint32_t pos,
+                                    bool bits_only = false) {
+  const uint32_t nwords = (mask + 1u) >> 6, wmask = nwords - 1u;
+  uint32_t w = pos >> 6;
+  unsigned long long z = ~occ[w] & (~0ull << (pos & 63u));
+  for (uint32_t walked = 0; walked <= nwords + FAR_UNIT_WORDS;) {
+    if (z) {
+      const uint32_t p = (w << 6) + (uint32_t)__ffsll(z) - 1u;
+      if (bits_only) return p;
+      const uint64_t c = ld_relaxed(&cells[p]);
+      if (c == 0 || cell_key(c) == Y) return p;
+      z &= z - 1;                                      // taken since the scan by another key: on
+      continue;
+    }
+    w = (w + 1) & wmask;
+    walked++;
+    if ((w & (FAR_UNIT_WORDS - 1u)) == 0) {            // a unit begins: those without a free cell are stepped over whole
+      while (walked <= nwords + FAR_UNIT_WORDS && zeros[w >> (FAR_UNIT_LG - 6)] == 0) { w = (w + FAR_UNIT_WORDS) & wmask; walked += FAR_UNIT_WORDS; }
+    }
+    z = ~occ[w];
+  }
+  return PROBE_NONE;
+}
+
+// CLAIMED inserts of the far join.  The new far keys of a clustered row all walk to the same free cells -- the holes of their run,
+// then the cells behind it -- and each insert must see the one before it: 2 000 new keys of one row were 2 000 dependent
+// compare-and-swaps on the cell at the front, the pass's critical path.  With the join such a key is known to be absent and the
+// free cells of its row are the clear bits of the occupancy words, so an insert CLAIMS its cell there first: the first clear bit
+// at/after the key's own first free cell that it manages to set (one atomic OR per attempt; the word the OR returns is fresh, so
+// a crowded front costs one atomic per 64 cells, not one per cell) names a cell nobody else will claim; the key is then stored
+// with a compare-and-swap (a cell that a plain insert took in the meantime just sends the claimer on).  The table ends as SOME
+// order of the reference's inserts would leave it (src/smatrix.c:343-380): every cell between a key's home and its own was
+// taken at the scan or has its bit set -- claimed by an op that holds a ticket and stores its key there, or found taken.
+// One op per key does this (the claim word of the key's entry in F); another op naming the same new key is deferred to the
+// retry, which finds the key in place.  The words are scratch of this batch (k_far_scan rewrites them).
+template <int OP>
+__device__ inline uint32_t far_claim_insert(DirSlot* d, const uint4 s, uint8_t* arena, uint32_t Y, uint32_t V, uint32_t e0,
+                                            unsigned long long* occ, const uint32_t* zeros, uint64_t* cells, uint32_t mask, bool* deferred,
+                                            uint32_t* where) {
+  const uint32_t lg = meta_lg(s.x);
+  uint32_t* ticket = nullptr;                        // src/smatrix.c:346: insert only while used <= size/2 (as in apply_row)
+  if (lg >= BIG_LG) {
+    SubCtr* subs = row_subs(arena, s.z, lg);
+    const uint32_t k0 = (blockIdx.x * 5u + threadIdx.x) & (SUBS - 1u);
+    ticket = sub_ticket(subs + k0);
+    if (!ticket) ticket = sub_ticket_elsewhere(subs, k0);
+    if (!ticket) { *deferred = true; return 0; }
+  } else {
+    if (s.w > (mask + 1u) / 2u) { *deferred = true; return 0; }
+    ticket = &d->used;
+    if (atomicAdd(ticket, 1u) > (mask + 1u) / 2u) { atomicSub(ticket, 1u); *deferred = true; return 0; }
+  }
+  const uint32_t first = OP == OP_DECR ? 0u - V : V;
+  const uint32_t nwords = (mask + 1u) >> 6, wmask = nwords - 1u;
+  uint32_t w = e0 >> 6;
+  unsigned long long z = ~__hip_atomic_load(&occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (~0ull << (e0 & 63u));
+  for (uint32_t walked = 0; walked <= nwords + FAR_UNIT_WORDS;) {
+    if (z) {
+      const uint32_t b = (uint32_t)__ffsll(z) - 1u;
+      const unsigned long long bit = 1ull << b;
+      const unsigned long long old = atomicOr(&occ[w], bit);
+      z &= ~(old | bit);                              // (what the word really held: the bits others have set since are not tried)
+      if (old & bit) continue;                        // somebody else's
+      const uint32_t pos = (w << 6) + b;
+      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull, (unsigned long long)pack_cell(Y, first));
+      if (prev == 0) { *where = pos; return first; }
+      if (cell_key(prev) == Y) {                      // (not with one op per key; kept for safety: the cell is updated, the ticket goes back)
+        atomicSub(ticket, 1u);
+        uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
+        *where = pos;
+        return OP == OP_INCR ? atomicAdd(vp, V) + V : atomicSub(vp, V) - V;
+      }
+      continue;                                       // a plain insert took the cell meanwhile: the claim stands for it, on
+    }
+    w = (w + 1) & wmask;
+    walked++;
+    if ((w & (FAR_UNIT_WORDS - 1u)) == 0)             // units without a free cell at the scan are full for good
+      while (walked <= nwords + FAR_UNIT_WORDS && zeros[w >> (FAR_UNIT_LG - 6)] == 0) { w = (w + FAR_UNIT_WORDS) & wmask; walked += FAR_UNIT_WORDS; }
+    z = ~__hip_atomic_load(&occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  atomicSub(ticket, 1u);
+  *deferred = true;
+  return 0;
 }
 
 struct LongProbe {
@@ -421,24 +556,6 @@ struct LongProbe {
 #define SMX_PROBE_BUDGET 48
 #endif
 constexpr uint32_t PROBE_BUDGET = SMX_PROBE_BUDGET;
-constexpr uint32_t PROBE_NONE = 0xFFFFFFFFu;
-
-// the position of the r-th (0-based) set bit of w; r < popcount(w)
-__device__ inline uint32_t select_bit(unsigned long long w, uint32_t r) {
-  uint32_t pos = 0;
-  uint32_t lo = (uint32_t)w, c = __popc(lo);
-  if (r >= c) { r -= c; pos = 32; lo = (uint32_t)(w >> 32); }
-  c = __popc(lo & 0xFFFFu);
-  if (r >= c) { r -= c; pos += 16; lo >>= 16; }
-  c = __popc(lo & 0xFFu);
-  if (r >= c) { r -= c; pos += 8; lo >>= 8; }
-  c = __popc(lo & 0xFu);
-  if (r >= c) { r -= c; pos += 4; lo >>= 4; }
-  c = __popc(lo & 0x3u);
-  if (r >= c) { r -= c; pos += 2; lo >>= 2; }
-  if (r >= (lo & 1u)) pos += 1;
-  return pos;
-}
 
 // Called by ALL lanes of a wave together (convergent).  Lanes with `need` get the first slot at/after `pos`
 // (cyclically, at most one full turn) whose key is Y or that is empty; PROBE_NONE if the table has neither.
@@ -689,7 +806,8 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
 // batch took 4 ms for 4 500 ops.
 // HM: 0 the matrix has no hint table (ArenaHead; the instantiation every scrambled-id stream runs: nothing of it is compiled in),
 //     1 it has one, 2 look (the wave-per-op kernel: clustered tables only)
-template <int OP, bool WPO = false, int HM = 0>
+// FAR: the pass in front of prep of a clustered write batch, with the batch's far join at hand (ArenaHead::far_on)
+template <int OP, bool WPO = false, int HM = 0, bool FAR = false>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -702,7 +820,9 @@ __device__ __forceinline__ void apply_body(
   //  and the ops at the front would be applied a SECOND time -- round 3, found by the 2^31 + 2^27-op batch test)
   const uint64_t n_lanes = WPO ? (uint64_t)n * 64u : (uint64_t)n;
   const bool has_hints = HM == 1 || (HM == 2 && reinterpret_cast<const ArenaHead*>(arena)->hint_mask != 0);       // (wave-uniform)
-  const uint32_t budget = has_hints ? HINT_BUDGET : PROBE_BUDGET;
+  // (a wave per op with the join at hand: the lane looks at the home cell only -- nine dependent loads of the lane's own probe
+  //  were half of such a pass's time; the wave's first window covers them in one load)
+  const uint32_t budget = WPO && FAR ? 0u : has_hints ? HINT_BUDGET : PROBE_BUDGET;
   // (clustered matrices: long probes go by the rows' at-home bitmaps, and inserts keep them up to date -- HOME_LG)
   const bool use_home = HM != 0 && reinterpret_cast<const ArenaHead*>(arena)->home_on != 0;                          // (wave-uniform)
   for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n_lanes; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
@@ -714,6 +834,13 @@ __device__ __forceinline__ void apply_body(
     LongProbe lp{false, nullptr, 0, 0};
     uint4 s = {0, 0, 0, 0};
     DirSlot* d = nullptr;
+    // (measurement runs, SMATRIX_REST_DBG: where a wave-per-op pass with the far join spends its cycles)
+    unsigned long long* tdbg = WPO && FAR ? reinterpret_cast<const ArenaHead*>(arena)->dbg : nullptr;
+    unsigned long long* hdbg = FAR && !WPO ? reinterpret_cast<const ArenaHead*>(arena)->dbg : nullptr;     // (a lane per op: how long a wave's trip takes, log2 buckets)
+    const long long h0 = hdbg ? clock64() : 0;
+    long long h_find = 0, h_walk = 0, h_ins = 0;
+    long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+    if (tdbg) tc0 = clock64();
     if (live) {
       j = idx ? idx[t] : t;
       const size_t at = (size_t)j * st;
@@ -738,29 +865,98 @@ __device__ __forceinline__ void apply_body(
     // the far join of this batch (the wave-per-op pass in front of prep): the key's cell is known, or the key is known to have
     // been absent when the tables were scanned and the probe goes by the occupancy words
     const unsigned long long* occ = nullptr;
-    if (WPO && HM == 2 && lp.need) {
+    const uint32_t* zer = nullptr;
+    bool ranked = false;                                    // this op may insert its (absent) key by claiming a free cell in the occupancy words: far_claim_insert
+    if (tdbg) tc1 = clock64();
+    if (FAR && lp.need) {
       const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
       if (ah->far_on && !ah->twins) {
+        const long long hf0 = hdbg ? clock64() : 0;
         const FarHit fh = far_find(arena, lp.cells, Y);
-        if (ah->dbg) atomicAdd(&ah->dbg[16 + fh.state], 1ull);
+        if (hdbg) h_find = clock64() - hf0;
+        if (ah->dbg && !hdbg) atomicAdd(&ah->dbg[16 + fh.state], 1ull);
         if (fh.state == FAR_FOUND) {
           if (has_hints) was_long = ((fh.slot - Y) & lp.mask) > PROBE_BUDGET;
           lp.need = false;
           r = apply_row<OP, true, 1>(d, s, arena, Y, V, fh.slot, &deferred, &lp);
           p_coop = fh.slot;
-        } else if (fh.state == FAR_ABSENT) occ = fh.occ;
+        } else if (fh.state == FAR_ABSENT) {
+          occ = fh.occ;
+          if ((OP == OP_INCR || OP == OP_DECR) && !ah->far_overflow) {
+            // one op per new key inserts it; another one naming the same key waits for the retry (it finds the key in place)
+            if (atomicCAS(&fh.entry->w, 0u, 1u) == 0u) ranked = true;
+            else { lp.need = false; deferred = true; was_long = true; }
+          }
+          if (!WPO && lp.need) {
+            // a lane per op: the lane walks by the occupancy words itself (far_walk), all lanes of the wave side by side
+            lp.need = false;
+            was_long = true;
+            const long long hw0 = hdbg ? clock64() : 0;
+            const uint32_t p = far_walk(lp.cells, lp.mask, fh.occ, fh.zeros, Y, lp.pos, ranked);
+            if (hdbg) { h_walk = clock64() - hw0; atomicAdd(&hdbg[40], 1ull); atomicAdd(&hdbg[41], (unsigned long long)((p - lp.pos) & lp.mask)); atomicMax(&hdbg[42], (unsigned long long)((p - lp.pos) & lp.mask));
+                        atomicAdd(&hdbg[43 + min(meta_lg(s.x) / 4u, 5u)], 1ull); }
+            const long long hi0 = hdbg ? clock64() : 0;
+            if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; }
+            else if (OP != OP_GET && OP != OP_SET && ranked) {
+              // (the front = the first cell that was free at the scan: the same for every op that walks up to it, whenever it comes)
+              uint32_t where = p;
+              r = far_claim_insert<OP == OP_DECR ? OP_DECR : OP_INCR>(d, s, arena, Y, V, p, const_cast<unsigned long long*>(fh.occ), fh.zeros, const_cast<uint64_t*>(lp.cells), lp.mask, &deferred, &where);
+              p_coop = where;
+            } else {
+              r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
+              p_coop = p;
+            }
+            occ = nullptr;
+            ranked = false;                                 // (whatever is left of this op walks the old way)
+            if (hdbg) h_ins = clock64() - hi0;
+          }
+          zer = fh.zeros;
+        }
       }
     }
+    if (tdbg) tc2 = clock64();
+    long long t_coop = 0;
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
+      const long long ta = tdbg ? clock64() : 0;
       const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home, occ);
+      if (tdbg) t_coop += clock64() - ta;
       if (lp.need) {
         lp.need = false;
         if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; was_long = true; }   // neither the key nor an empty cell: prep grows the row
         else {
           if (has_hints) was_long = ((p - Y) & lp.mask) > PROBE_BUDGET;
-          r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
-          p_coop = p;
+          if (OP != OP_GET && OP != OP_SET && ranked && ld_relaxed(&lp.cells[p]) == 0) {
+            // the first cell that was free at the scan is still free: the key goes in by rank from this front
+            ranked = false;
+            uint32_t where = p;
+            r = far_claim_insert<OP == OP_DECR ? OP_DECR : OP_INCR>(d, s, arena, Y, V, p, const_cast<unsigned long long*>(occ), zer, const_cast<uint64_t*>(lp.cells), lp.mask, &deferred, &where);
+            p_coop = where;
+          } else {
+            r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
+            p_coop = p;
+          }
         }
+      }
+    }
+    if (hdbg) {
+      // per wave: the longest lane of each phase, and the whole trip up to here
+      long long mf = h_find, mw = h_walk, mi = h_ins;
+#pragma unroll
+      for (int dd = 32; dd >= 1; dd >>= 1) {
+        mf = max(mf, (long long)__shfl_xor((int)mf, dd)); mw = max(mw, (long long)__shfl_xor((int)mw, dd)); mi = max(mi, (long long)__shfl_xor((int)mi, dd));
+      }
+      if (__lane_id() == 0) {
+        const long long tot = clock64() - h0;
+        atomicAdd(&hdbg[20], (unsigned long long)mf); atomicAdd(&hdbg[21], (unsigned long long)mw); atomicAdd(&hdbg[22], (unsigned long long)mi);
+        atomicAdd(&hdbg[23], (unsigned long long)tot); atomicAdd(&hdbg[24], 1ull);
+        atomicMax(&hdbg[25], (unsigned long long)mw); atomicMax(&hdbg[26], (unsigned long long)mi); atomicMax(&hdbg[27], (unsigned long long)tot);
+      }
+    }
+    if (tdbg) {
+      tc3 = clock64();
+      if (__lane_id() == 0 && live) {
+        atomicAdd(&tdbg[20], (unsigned long long)(tc1 - tc0)); atomicAdd(&tdbg[21], (unsigned long long)(tc2 - tc1));
+        atomicAdd(&tdbg[22], (unsigned long long)t_coop); atomicAdd(&tdbg[23], (unsigned long long)(tc3 - tc2 - t_coop)); atomicAdd(&tdbg[24], 1ull);
       }
     }
     if (OP != OP_GET && !WPO) {                           // (the host's evidence for "this table is clustered")
@@ -978,6 +1174,26 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
     for (uint32_t i = threadIdx.x; i < l_n; i += DEDUP_THREADS) reps[l_base + i] = l_rep[i];
     __syncthreads();
   }
+}
+
+// The pass in front of prep when the batch's far join is there: a LANE per op again.  With the join a far op is a table look-up
+// and, for a new key, a look at a few occupancy words -- no walk worth a whole wave (k_apply_wpo: 26 us per op and wave).
+template <int OP>
+__global__ __launch_bounds__(256) void k_apply_far(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
+  apply_body<OP, false, 1, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+}
+
+// ... and the same a wave per op (measured faster: 2.6 against 3.5-4.6 ms per dense-id batch -- a wave with 64 far ops still
+// takes their cooperative walks one after the other)
+template <int OP>
+__global__ __launch_bounds__(256) void k_apply_wpo_far(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
+  apply_body<OP, true, 2, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 template <int OP>
@@ -3232,33 +3448,50 @@ __global__ __launch_bounds__(256) void k_home_rebuild(const DirSlot* dir, const 
 }
 
 // ---- the far join's kernels (see "far join" above) ---------------------------------------------------------------------------
-// k_far_plan (one workgroup): the listed big rows (k_home_list) get their units -- an exclusive scan of 2^(lg - FAR_UNIT_LG) --,
-// the unit -> row map, and their entry {row block, 0} -> first unit in F.  Rows that do not fit the capacities are left out.
-__global__ __launch_bounds__(1024) void k_far_plan(Ctl* ctl, const DirSlot* dir, const uint32_t* list, uint32_t cap_rows, uint32_t* unit_first,
-                                                   uint32_t* unit_row, uint32_t cap_units, uint4* tab, uint32_t tmask) {
-  __shared__ uint32_t l_sum[1024];
-  const uint32_t n = min(aload(&ctl->n_big), cap_rows), tid = threadIdx.x;
-  const uint32_t per = (n + 1023u) / 1024u, i0 = min(n, tid * per), i1 = min(n, i0 + per);
-  uint32_t mine = 0;
-  for (uint32_t i = i0; i < i1; i++) mine += 1u << (meta_lg(dir[list[i]].meta) - FAR_UNIT_LG);
-  l_sum[tid] = mine;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {                           // inclusive scan
-    const uint32_t v = tid >= d ? l_sum[tid - d] : 0u;
+// k_far_rows: every row of >= 2^FAR_ROW_LG cells takes its units (one atomic add: the order does not matter), fills the unit ->
+// row map and enters F as {row block, 0} -> first unit.  A row that does not fit the capacities is left out.
+__global__ __launch_bounds__(256) void k_far_rows(Ctl* ctl, const DirSlot* dir, uint32_t dir_size, uint32_t* unit_row, uint32_t cap_units, uint4* tab,
+                                                  uint32_t tmask) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t h0 = blockIdx.x * blockDim.x; h0 < dir_size; h0 += gridDim.x * blockDim.x) {      // (block-uniform: dir_size is a multiple of 256)
+    const uint32_t h = h0 + threadIdx.x;
+    const DirSlot d = dir[h];
+    const bool big = (d.meta & META_USED) && d.base != 0 && meta_lg(d.meta) >= FAR_ROW_LG;
+    const uint32_t units = big ? 1u << (meta_lg(d.meta) - FAR_UNIT_LG) : 0u;
+    // one reservation per WAVE (10^5 rows adding to one word one by one were 1 ms of every batch)
+    uint32_t incl = units;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, dd);
+      if ((int)lane >= dd) incl += o;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const uint64_t bm = __ballot(big);
+    // ... and per WORKGROUP (every atomic on these two words queues at the memory side: 65 000 wave-level adds were still 1 ms)
+    __shared__ uint32_t l_tot[4], l_big[4], l_base;
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 0) { l_tot[wv] = total; l_big[wv] = (uint32_t)__popcll(bm); }
     __syncthreads();
-    l_sum[tid] += v;
+    if (threadIdx.x == 0) {
+      const uint32_t t4 = l_tot[0] + l_tot[1] + l_tot[2] + l_tot[3], b4 = l_big[0] + l_big[1] + l_big[2] + l_big[3];
+      l_base = t4 ? atomicAdd(&ctl->n_units, t4) : 0u;
+      if (b4) atomicAdd(&ctl->n_big, b4);
+    }
     __syncthreads();
+    uint32_t base = l_base;
+    for (uint32_t q = 0; q < wv; q++) base += l_tot[q];
+    __syncthreads();                                                       // (the scratch is reused by the next trip)
+    if (!bm) continue;
+    if (!unit_row) continue;                                               // (unit_row == nullptr: counting only, the host sizes its buffers)
+    const uint32_t first = base + incl - units;
+    // the unit -> row map, a row at a time with the whole wave (the lane of a 2^21-cell row wrote its 4096 entries alone: 1 ms)
+    for (uint64_t todo = bm; todo; todo &= todo - 1) {                     // (wave-uniform)
+      const int src = __ffsll((unsigned long long)todo) - 1;
+      const uint32_t f = (uint32_t)__shfl((int)first, src), n = (uint32_t)__shfl((int)units, src), hh = h0 + (threadIdx.x & ~63u) + (uint32_t)src;
+      for (uint32_t u = lane; u < n && (uint64_t)f + u < cap_units; u += 64) unit_row[f + u] = hh;           // (every unit below the capacity names ITS row)
+    }
+    if (big && (uint64_t)first + units <= cap_units) far_insert(tab, tmask, d.base, 0u, first);
   }
-  uint32_t first = l_sum[tid] - mine;
-  for (uint32_t i = i0; i < i1; i++) {
-    const DirSlot d = dir[list[i]];
-    const uint32_t units = 1u << (meta_lg(d.meta) - FAR_UNIT_LG);
-    unit_first[i] = first;
-    for (uint32_t u = 0; u < units && first + u < cap_units; u++) unit_row[first + u] = i;
-    if (first + units <= cap_units) far_insert(tab, tmask, d.base, 0u, first);     // (a row that does not fit whole is not in F)
-    first += units;
-  }
-  if (tid == 1023) ctl->n_units = l_sum[1023];
 }
 
 // k_far_keys: the deferred ops whose probe outruns the lane's budget on a row of >= 2^HOME_LG cells (what the wave-per-op pass is
@@ -3271,7 +3504,7 @@ __global__ __launch_bounds__(256) void k_far_keys(const Ctl* ctl, DirSlot* dir, 
     const size_t at = (size_t)idx[t] * st;
     const uint32_t Y = ys[at];
     uint4 s;
-    if (Y == 0 || !dir_find(dir, dmask, xs[at], &s) || s.z == 0 || meta_lg(s.x) < HOME_LG) continue;
+    if (Y == 0 || !dir_find(dir, dmask, xs[at], &s) || s.z == 0 || meta_lg(s.x) < FAR_ROW_LG) continue;
     const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
     const uint64_t* cells = row_cells(arena, s.z);
     uint32_t pos = Y & mask;
@@ -3281,40 +3514,42 @@ __global__ __launch_bounds__(256) void k_far_keys(const Ctl* ctl, DirSlot* dir, 
       if (cell_key(c) == Y || c == 0) { far = false; break; }
       pos = (pos + 1) & mask;
     }
-    if (far) far_insert(tab, tmask, s.z, Y, FAR_NOT_FOUND);
+    if (far && !far_insert(tab, tmask, s.z, Y, FAR_NOT_FOUND)) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
   }
+  // (ops beyond the limit are not in the table: two ops naming one new key could then take different paths -- no claimed inserts)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && aload(&ctl->n_prev) > limit) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
 }
 
-// k_far_scan: a wave per unit of 1024 cells: the occupancy words (a (0, v) cell counts as free: it may turn back into an empty
-// one, quirk Q1), and every displaced cell's slot into its key's entry of F, if it has one.
-__global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot* dir, const uint32_t* list, const uint32_t* unit_first,
-                                                  const uint32_t* unit_row, uint32_t cap_units, uint8_t* arena, uint4* tab, uint32_t tmask,
-                                                  unsigned long long* occ) {
+// k_far_scan: a wave per unit: the occupancy words (a (0, v) cell counts as free: it may turn back into an empty one, quirk Q1),
+// the unit's count of free cells, and every displaced cell's slot into its key's entry of F, if it has one.
+__global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot* dir, const uint32_t* unit_row, uint32_t cap_units, uint8_t* arena,
+                                                  uint4* tab, uint32_t tmask, unsigned long long* occ, uint32_t* zeros) {
   const uint32_t n_units = min(aload(&ctl->n_units), cap_units);
   const uint32_t lane = threadIdx.x & 63u, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < n_units; u += nwaves) {     // (wave-uniform)
-    const uint32_t i = unit_row[u];
-    const DirSlot d = dir[list[i]];
-    const uint32_t mask = (1u << meta_lg(d.meta)) - 1u, p0 = (u - unit_first[i]) << FAR_UNIT_LG;
-    if (unit_first[i] + ((mask + 1u) >> FAR_UNIT_LG) > cap_units) continue;           // (the row does not fit whole: not in F)
+    const DirSlot d = dir[unit_row[u]];
+    const uint32_t mask = (1u << meta_lg(d.meta)) - 1u;
+    const uint4* row = far_entry(tab, tmask, d.base, 0u);                  // (a row that did not fit whole has no entry: its units are skipped)
+    if (!row) { if (lane == 0) zeros[u] = 0xFFFFFFFFu; continue; }
+    const uint32_t p0 = (u - row->z) << FAR_UNIT_LG;
     const uint64_t* cells = row_cells(arena, d.base) + p0;
+    uint64_t c[FAR_UNIT_WORDS];
 #pragma unroll
-    for (uint32_t q0 = 0; q0 < 16; q0 += 8) {
-      uint64_t c[8];
+    for (uint32_t q = 0; q < FAR_UNIT_WORDS; q++) c[q] = cells[q * 64u + lane];
+    uint32_t free_cells = 0;
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) c[q] = cells[(q0 + q) * 64u + lane];
-#pragma unroll
-      for (uint32_t q = 0; q < 8; q++) {
-        const uint32_t p = p0 + (q0 + q) * 64u + lane, key = cell_key(c[q]);
-        const bool taken = c[q] != 0 && key != 0;
-        const uint64_t m = __ballot(taken);
-        if (lane == 0) occ[(size_t)u * 16u + q0 + q] = m;
-        if (taken && (key & mask) != p) {
-          uint4* e = far_entry(tab, tmask, d.base, key);
-          if (e) e->z = p;
-        }
+    for (uint32_t q = 0; q < FAR_UNIT_WORDS; q++) {
+      const uint32_t p = p0 + q * 64u + lane, key = cell_key(c[q]);
+      const bool taken = c[q] != 0 && key != 0;
+      const uint64_t m = __ballot(taken);
+      free_cells += 64u - (uint32_t)__popcll(m);
+      if (lane == 0) occ[(size_t)u * FAR_UNIT_WORDS + q] = m;
+      if (taken && (key & mask) != p) {
+        uint4* e = far_entry(tab, tmask, d.base, key);
+        if (e) e->z = p;
       }
     }
+    if (lane == 0) zeros[u] = free_cells;
   }
 }
 

@@ -667,8 +667,10 @@ struct Matrix {
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
   // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
   bool far_join = true;
+  bool far_lanes = false;               // SMATRIX_FAR_LANES=1 (measurements): the pass in front of prep a lane per op, every lane walking the occupancy
+                                        // words itself -- slower (4.0 against 2.8 ms per dense-id batch: a wave's trip takes as long as its slowest lane)
   DevBuf<uint4> far_tab;
-  DevBuf<uint32_t> far_list, far_unit_first, far_unit_row;
+  DevBuf<uint32_t> far_unit_row, far_zeros;
   DevBuf<unsigned long long> far_occ;
   uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
   uint32_t far_rows_seen = 0, far_units_seen = 0;   // rows of >= 2^HOME_LG cells / their 1024-cell units when they were last counted
@@ -829,30 +831,45 @@ void clustered_sync(Matrix* m, hipStream_t s) {
 // estimate -- what does not fit is left out of the table and takes the old walk.  Returns false when nothing was enqueued.
 bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32_t* x, const uint32_t* y, uint32_t est_nd) {
   if (!m->far_join || !m->home_on || m->dir_used == 0) return false;
-  const uint32_t cap_rows = (uint32_t)std::min<uint64_t>(m->dir_used, (uint64_t)m->far_rows_seen * 5 / 4 + 1024);
-  const uint32_t cap_units = (uint32_t)std::min<uint64_t>(m->arena.mapped >> (FAR_UNIT_LG + 3), (uint64_t)m->far_units_seen * 5 / 4 + 8192);
+  if (m->far_units_seen == 0) {
+    // the first join of this matrix: how many rows and units there are is counted once, with a read-back
+    HIP_OK(hipMemsetAsync(&m->d_ctl->n_big, 0, 8, s));
+    hipLaunchKernelGGL(k_far_rows, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size, (uint32_t*)nullptr, 0u,
+                       (uint4*)nullptr, 0u);
+    HIP_OK(hipGetLastError());
+    uint32_t two[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(two, &m->d_ctl->n_big, 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    m->far_rows_seen = two[0]; m->far_units_seen = std::max(two[1], 1u);
+  }
+  const uint32_t cap_rows = (uint32_t)std::min<uint64_t>(m->dir_used, (uint64_t)m->far_rows_seen * 5 / 4 + 4096);
+  const uint32_t cap_units = (uint32_t)std::min<uint64_t>(m->arena.mapped >> (FAR_UNIT_LG + 3), (uint64_t)m->far_units_seen * 5 / 4 + 32768);
   uint32_t lg = 16;
   while (lg < 23 && (1ull << lg) < 4ull * est_nd + 2ull * cap_rows) lg++;
-  m->far_list.need(cap_rows); m->far_unit_first.need(cap_rows); m->far_unit_row.need(cap_units);
-  const bool moved = m->far_tab.cap < ((size_t)1 << lg) || m->far_occ.cap < (size_t)cap_units * 16;
-  m->far_tab.need((size_t)1 << lg); m->far_occ.need((size_t)cap_units * 16);
+  m->far_unit_row.need(cap_units);
+  const bool moved = m->far_tab.cap < ((size_t)1 << lg) || m->far_occ.cap < (size_t)cap_units * FAR_UNIT_WORDS || m->far_zeros.cap < cap_units;
+  m->far_tab.need((size_t)1 << lg); m->far_occ.need((size_t)cap_units * FAR_UNIT_WORDS); m->far_zeros.need(cap_units);
   if (moved || m->far_tab_lg != lg) {
-    struct { uint32_t mask; uint4* tab; const unsigned long long* occ; } __attribute__((packed)) w = {(1u << lg) - 1u, m->far_tab.p, m->far_occ.p};
-    static_assert(sizeof(w) == 20 && offsetof(ArenaHead, far_tab) == offsetof(ArenaHead, far_mask) + 4 && offsetof(ArenaHead, far_occ) == offsetof(ArenaHead, far_tab) + 8, "ArenaHead layout");
+    struct { uint32_t mask; uint4* tab; const unsigned long long* occ; const uint32_t* zeros; } __attribute__((packed)) w = {(1u << lg) - 1u, m->far_tab.p, m->far_occ.p, m->far_zeros.p};
+    static_assert(sizeof(w) == 28 && offsetof(ArenaHead, far_tab) == offsetof(ArenaHead, far_mask) + 4 && offsetof(ArenaHead, far_occ) == offsetof(ArenaHead, far_tab) + 8 &&
+                  offsetof(ArenaHead, far_zeros) == offsetof(ArenaHead, far_occ) + 8, "ArenaHead layout");
     HIP_OK(hipMemcpyAsync(m->arena.base + offsetof(ArenaHead, far_mask), &w, sizeof(w), hipMemcpyHostToDevice, s));
     HIP_OK(hipStreamSynchronize(s));                       // (`w` is on the stack; rare: the buffers moved)
     m->far_tab_lg = lg;
   }
   const uint32_t tmask = (1u << lg) - 1u;
   HIP_OK(hipMemsetAsync(m->far_tab.p, 0, (size_t)16 << lg, s));
+  arena_head_set(m, offsetof(ArenaHead, far_overflow), 0u, s);
   HIP_OK(hipMemsetAsync(&m->d_ctl->n_big, 0, 8, s));       // n_big, n_units
-  hipLaunchKernelGGL(k_home_list, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_dir, m->dir_size, m->far_list.p, &m->d_ctl->n_big, cap_rows);
-  hipLaunchKernelGGL(k_far_plan, dim3(1), dim3(1024), 0, s, m->d_ctl, m->d_dir, m->far_list.p, cap_rows, m->far_unit_first.p, m->far_unit_row.p, cap_units,
+  hipLaunchKernelGGL(k_far_rows, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size, m->far_unit_row.p, cap_units,
                      m->far_tab.p, tmask);
+  DBG_STEP(m, s, "k_far_rows");
   hipLaunchKernelGGL(k_far_keys, dim3(std::min<uint32_t>(blocks_for(est_nd), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, dl, x, y,
                      m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u);
-  hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 16384)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_list.p,
-                     m->far_unit_first.p, m->far_unit_row.p, cap_units, m->arena.base, m->far_tab.p, tmask, m->far_occ.p);
+  DBG_STEP(m, s, "k_far_keys");
+  hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 32768)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_unit_row.p, cap_units,
+                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p);
+  DBG_STEP(m, s, "k_far_scan");
   HIP_OK(hipGetLastError());
   arena_head_set(m, offsetof(ArenaHead, far_on), 1u, s);
   return true;
@@ -1449,10 +1466,23 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       uint32_t* dlp = m->defer[1].p;
       hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
       far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n));
+      if (far_joined && !m->far_lanes) {
+        const dim3 wgrid(65536);
+        if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+        else hipLaunchKernelGGL((k_apply_wpo_far<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+      } else if (far_joined) {
+        // (SMATRIX_FAR_LANES=1, measurements: with the join a lane per op, see k_apply_far)
+        const uint32_t est = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n);
+        const dim3 fgrid(std::min<uint32_t>(blocks_for(est), 16384));
+        if (op == OP_INCR) hipLaunchKernelGGL((k_apply_far<OP_INCR>), fgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+        else hipLaunchKernelGGL((k_apply_far<OP_DECR>), fgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+      } else {
       const dim3 wgrid(65536);
       if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
       else hipLaunchKernelGGL((k_apply_wpo<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
+      }
       HIP_OK(hipGetLastError());
+      DBG_STEP(m, s, "the pass in front of prep");
       dl = dlp;
     }
     launch_prep(dl);
@@ -1883,10 +1913,11 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
+  if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
-    dev_malloc(&m->rest_dbg, 256);
-    HIP_OK(hipMemset(m->rest_dbg, 0, 256));
+    dev_malloc(&m->rest_dbg, 512);
+    HIP_OK(hipMemset(m->rest_dbg, 0, 512));
     HIP_OK(hipMemcpy(m->arena.base + offsetof(ArenaHead, dbg), &m->rest_dbg, 8, hipMemcpyHostToDevice));
   }
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
@@ -1935,9 +1966,14 @@ void smatrix_close(smatrix_t* self) {
   if (m) {
     set_device(m);
     if (m->rest_dbg) {
-      unsigned long long c[32];
-      HIP_OK(hipMemcpy(c, m->rest_dbg, 256, hipMemcpyDeviceToHost));
+      unsigned long long c[64];
+      HIP_OK(hipMemcpy(c, m->rest_dbg, 512, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smatrix] far join, long probes of the wave-per-op pass: not in the table %llu, cell known %llu, absent at the scan %llu\n", c[16], c[17], c[18]);
+      if (c[40]) fprintf(stderr, "[smatrix] far_walk: %llu walks, %.0f cells on average, longest %llu; by row size 2^(4k..): %llu %llu %llu %llu %llu %llu\n", c[40], c[41] / (double)c[40], c[42],
+                         c[43], c[44], c[45], c[46], c[47], c[48]);
+      if (c[24]) fprintf(stderr, "[smatrix] (lane-per-op pass: per wave trip, longest lane: join look-up / walk / insert / whole trip; then the maxima of walk, insert, trip: %llu %llu %llu)\n", c[25], c[26], c[27]);
+      if (c[24]) fprintf(stderr, "[smatrix] wave-per-op pass with the join, cycles per op: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f  (%llu ops)\n",
+                         c[20] / (double)c[24], c[21] / (double)c[24], c[22] / (double)c[24], c[23] / (double)c[24], c[24]);
       fprintf(stderr, "[smatrix] k_grow_rest_lds: steps %llu rounds %llu | most steps of a wave %llu, most rounds %llu | trips %llu, most of a wave %llu | per round: losers %.2f blocked %.2f committed %.2f\n",
               c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
       (void)hipFree(m->rest_dbg);
@@ -1965,7 +2001,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_small) (void)hipHostFree(m->h_small);
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
-      m->far_tab.release(); m->far_list.release(); m->far_unit_first.release(); m->far_unit_row.release(); m->far_occ.release();
+      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);

@@ -6,5 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/kt_dense -- python3 $R/tools/probe/dense_steps.py ${1:-24} 2>/dev/null | tail -2
 cd $R
 python tools/probe/kernel_sums_window.py gpurun_out/kt_dense ${2:-8}
+if [ -n "$3" ]; then python tools/probe/kernel_sums_window.py gpurun_out/kt_dense $3 $4; fi
 python tools/probe/step_kernels.py gpurun_out/kt_dense | tail -2 | cut -c1-900
 rm -rf gpurun_out/kt_dense
