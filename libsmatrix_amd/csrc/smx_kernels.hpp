@@ -137,6 +137,7 @@ struct Ctl {
   uint32_t spec_nkind0[4];
   // ---- the far join (k_home_list / k_far_plan): rows of >= 2^HOME_LG cells and their 1024-cell units, as of the last batch that ran it
   uint32_t n_big, n_units;
+  uint32_t far_nd, pad_far;      // ops in the list the join was last built for (k_far_keys): the host sizes the next table from it
 };
 constexpr size_t CTL_ROUND_BYTES = 64;    // one aligned fill
 static_assert(offsetof(Ctl, dir_used) == CTL_ROUND_BYTES, "the per-round part of Ctl is what ctl_reset_round zeroes");
@@ -3496,7 +3497,7 @@ __global__ __launch_bounds__(256) void k_far_rows(Ctl* ctl, const DirSlot* dir, 
 
 // k_far_keys: the deferred ops whose probe outruns the lane's budget on a row of >= 2^HOME_LG cells (what the wave-per-op pass is
 // going to find out again: nothing changes in between) enter F.  `limit`: ops beyond it are not entered (the table would fill up).
-__global__ __launch_bounds__(256) void k_far_keys(const Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, const uint32_t* idx,
+__global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, const uint32_t* idx,
                                                   const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t st, uint4* tab,
                                                   uint32_t tmask, uint32_t limit) {
   const uint32_t n = min(aload(&ctl->n_prev), limit);
@@ -3517,7 +3518,10 @@ __global__ __launch_bounds__(256) void k_far_keys(const Ctl* ctl, DirSlot* dir, 
     if (far && !far_insert(tab, tmask, s.z, Y, FAR_NOT_FOUND)) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
   }
   // (ops beyond the limit are not in the table: two ops naming one new key could then take different paths -- no claimed inserts)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && aload(&ctl->n_prev) > limit) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->far_nd = aload(&ctl->n_prev);
+    if (aload(&ctl->n_prev) > limit) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
+  }
 }
 
 // k_far_scan: a wave per unit: the occupancy words (a (0, v) cell counts as free: it may turn back into an empty one, quirk Q1),

@@ -673,6 +673,7 @@ struct Matrix {
   DevBuf<uint32_t> far_unit_row, far_zeros;
   DevBuf<unsigned long long> far_occ;
   uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
+  uint32_t far_nd_seen = 0;             // ops in the list the last join was built for
   uint32_t far_rows_seen = 0, far_units_seen = 0;   // rows of >= 2^HOME_LG cells / their 1024-cell units when they were last counted
   bool home_on = false;                 // the rows' at-home bitmaps (smx_kernels.hpp HOME_LG) are kept up to date and used by the probes: host mirror of ArenaHead::home_on
   uint32_t cold_min = 1u << 20;         // deferred ops from which it is tried (SMATRIX_COLD_MIN; 0 = never)
@@ -1460,12 +1461,16 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     // each of those probes to the end only to find the key present.  In the chained shape the whole deferred list takes
     // a wave-per-op pass first (k_apply_wpo); prep, the growth round and the retry see what that pass leaves: the ops
     // that really wait for a structure change.
-    const bool pre_pass = chained && m->clustered && (op == OP_INCR || op == OP_DECR);
+    // (round 5) with the far join the pass also pays in front of the FIRST prep of a batch the host drives round by round -- the
+    // young table's batches, whose deferred lists are the longest
+    const bool pre_pass = (chained || (round == 0 && idx == nullptr && !all_new && m->home_on && m->far_join && n >= (1u << 16))) && m->clustered &&
+                          (op == OP_INCR || op == OP_DECR);
     bool far_joined = false;
     if (pre_pass) {
       uint32_t* dlp = m->defer[1].p;
       hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
-      far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n));
+      // (the table is sized from the list the last join saw -- the folding kernel's deferred ops, 2-4x what the pass leaves)
+      far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(std::max<uint64_t>({2ull * m->spec_nd_prev, 3ull * m->far_nd_seen / 2, 1ull << 16}), cur_n));
       if (far_joined && !m->far_lanes) {
         const dim3 wgrid(65536);
         if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
@@ -1527,7 +1532,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       // bookkeeping of the round the host did not see, then on as if round 1 had just been read back
       const Ctl& c = *m->h_ctl;
       nd_chain0 = c.spec_nd0;
-      if (far_joined) { m->far_rows_seen = c.n_big; m->far_units_seen = c.n_units; }
+      if (far_joined) { m->far_rows_seen = c.n_big; m->far_units_seen = c.n_units; m->far_nd_seen = c.far_nd; }
       if (!m->in_cache_sync) m->last_nd0 = nd_chain0;
       m->expect_bulk = (uint64_t)nd_chain0 * 8 >= n;
       m->st.spec_chains++;
@@ -1568,6 +1573,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       if (nd_chain0 == 0) { structure_stable = true; break; }  // round 0 deferred nothing: the rest of the chain ran empty
       cur_n = nd_chain0;
       round = pre_pass ? 2 : 1;                                // (the next round writes the list that `dl` is NOT)
+    } else if (pre_pass) {
+      // the host-driven round 0 with the pass in front of prep: the list that is left sits in defer[1], so the next round is numbered 2
+      if (far_joined) { m->far_rows_seen = m->h_ctl->n_big; m->far_units_seen = m->h_ctl->n_units; m->far_nd_seen = m->h_ctl->far_nd; }
+      if (m->trace_rounds)
+        fprintf(stderr, "[smatrix] batch %llu round 0 with the pass in front of prep: ops=%u deferred=%u grow=%u rows=%u\n", (unsigned long long)m->st.batches, cur_n,
+                m->h_ctl->n_defer, m->h_ctl->n_tasks, m->h_ctl->dir_used);
     } else if (m->trace_rounds) {
       static thread_local double t_prev = 0;
       struct timespec ts;
@@ -1615,6 +1626,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     else if ((uint64_t)m->dir_used * 2 >= m->dir_size) grow_directory(m, 2, s);
     idx = dl;
     cur_n = nd;
+    if (pre_pass && !chained) round++;                       // (what is left sits in defer[1]: the next round writes defer[0])
   }
   // the chain is for batches near the steady shape (a few rounds: whatever its rounds 0 and 1 leave is finished by the
   // host-driven loop at no extra cost); young tables with many rounds per batch stay host-driven
