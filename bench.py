@@ -104,6 +104,7 @@ def short_line(full, detail_path=None):
             "matches_reference_checksums": g(full, "reference_checksums", "matches_reference"),
             "dense_ids_Mops_per_s": g(full, "dense_ids", "Mops_per_s"),
             "op_kinds_Gops_per_s": g(full, "op_kinds", "Gops_per_s"),
+            "host_api_Gops": {"incr": g(full, "host_api", "incr_Gops_per_s"), "get": g(full, "host_api", "get_Gops_per_s")},
             "config3": {"getrow_ms": g(full, "config3_getrow", "getrow_ms"), "frac": g(full, "config3_getrow", "roofline", "frac"),
                         "traffic": g(full, "config3_getrow", "roofline", "traffic"),
                         "verified": g(full, "config3_getrow", "verified_sum_of_values_eq_ops")},
@@ -111,7 +112,7 @@ def short_line(full, detail_path=None):
     for k, v in list(summ.items()):
         if v is None or v == {} or (isinstance(v, dict) and all(x is None for x in v.values())):
             del summ[k]
-    for k in ("sustained", "dense_ids", "op_kinds", "config3_getrow", "config5_file_1gpu", "reference_checksums"):
+    for k in ("sustained", "dense_ids", "op_kinds", "host_api", "config3_getrow", "config5_file_1gpu", "reference_checksums"):
         if isinstance(full.get(k), dict) and "error" in full[k]:
             summ[k + "_error"] = str(full[k]["error"])[:120]
     if summ:
@@ -797,6 +798,31 @@ def batch_size_leg(torch, dev, lg, stream):
             "note": "NOT `value` (that stays at 2^24-op batches, comparable across rounds): the same stream in %d batches of 2^%d ops" % (nb, lg)}
 
 
+def host_api_leg(B, calls=3):
+    """The host-pointer batch API -- what a JNI / Ruby batch binding calls with the caller's own arrays (the
+    reference's glue passes host values, src/smatrix_jni.c:95-111): 2^24-op incr and get calls from numpy arrays on the
+    config-2 stream, PCIe copies included (never `value`).  Calls of this size run as a three-stage pipeline over
+    2^21-op chunks (csrc/smx_runtime.hip host_pipeline)."""
+    import numpy as np
+    from libsmatrix_amd import SparseMatrix, Stream
+    gen = Stream("zipf", SEED, N_IDS, ZIPF_S, 1)
+    m = SparseMatrix()
+    ones = np.ones(B, np.uint32)
+    r = np.zeros(B, np.uint32); g = np.zeros(B, np.uint32)       # the caller's own result arrays, reused (what a binding passes)
+    ti, tg = [], []
+    ok = True
+    for k in range(calls + 1):
+        x, y = gen.fill(k * B, B)
+        t0 = time.perf_counter(); m.incr_batch(x, y, ones, out=r); t1 = time.perf_counter(); m.get_batch(x, y, out=g); t2 = time.perf_counter()
+        ok = ok and bool((g >= r).all()) and bool((r >= 1).all())
+        if k:                                                    # (call 0 creates the rows and the staging buffers)
+            ti.append(t1 - t0); tg.append(t2 - t1)
+    m.close(); gen.close()
+    return {"ops_per_call": B, "calls": calls, "incr_Gops_per_s": B / (sum(ti) / len(ti)) / 1e9, "get_Gops_per_s": B / (sum(tg) / len(tg)) / 1e9,
+            "incr_ms": [t * 1e3 for t in ti], "get_ms": [t * 1e3 for t in tg], "sanity": ok,
+            "note": "numpy arrays in pageable host memory; PCIe-inclusive, bounded by 16 B/op (incr) and 12 B/op (get) over the link"}
+
+
 def dense_ids_leg(torch, dev, B, stream, steps=24):
     from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
     gen = Stream("zipf", SEED, N_IDS, ZIPF_S, 0)
@@ -1244,6 +1270,8 @@ def main():
         extras["dense_ids"] = guarded(dense_ids_leg, torch, dev, B, stream)
         # (4) the four op kinds on the finished table
         extras["op_kinds"] = guarded(op_kinds_leg, torch, dev, m, xs[total_steps - 1], ys[total_steps - 1], B, stream)
+        # (5) the host-pointer batch API (numpy arrays, PCIe included): never `value`
+        extras["host_api"] = guarded(host_api_leg, B)
 
     total_ops = 2 * B * args.steps * world
     res = {

@@ -665,6 +665,7 @@ struct Matrix {
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
+  void* host_pipe = nullptr;            // HostPipe: the staging of large host-pointer batches (smatrix_apply_batch and friends)
   // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
   bool far_join = true;
   bool far_lanes = false;               // SMATRIX_FAR_LANES=1 (measurements): the pass in front of prep a lane per op, every lane walking the occupancy
@@ -1805,6 +1806,187 @@ void flusher_main(smatrix_t* self, Matrix* m) {
 }
 }  // namespace
 
+// ---- large host-pointer batches: staged in chunks, three stages overlapped -------------------------------------------------
+// smatrix_apply_batch / smatrix_rowlen_batch are what a batch binding calls with the caller's own arrays (the reference's glue
+// passes host values, src/smatrix_jni.c:95-111).  Round 4 copied the whole arrays with three pageable hipMemcpyAsync, ran the
+// kernels and copied the results back, one after the other: 1.3 G incr/s and 2.0 G get/s per 2^24-op call, against a PCIe bound
+// of 3.4-4.5 G/s -- a pageable copy is the runtime's single-threaded memcpy into its own pinned buffer.  Calls above two chunks
+// now run as a three-stage pipeline over chunks of 2^21 ops (SMATRIX_HOST_CHUNK_LG) and three sets of buffers:
+//   feeder thread   the caller's arrays -> pinned memory with a pool of copy threads, then host-to-device on its own stream
+//   calling thread  the op kernels of chunk k (the matrix lock is the caller's, as before), in order: a write batch's chunks
+//                   are applied one after the other, so duplicates resolve exactly as in one call (set: the later op wins)
+//   drain thread    device-to-host on a third stream, then pinned memory -> the caller's result array
+// so that the transfer of chunk k+1, the kernels of chunk k and the return of chunk k-1 overlap.
+struct CopyPool {                       // a few persistent threads that run memcpy slices
+  struct Slice { unsigned char* dst; const unsigned char* src; size_t len; };
+  std::vector<std::thread> th;
+  std::mutex mu, run_mu;
+  std::condition_variable cv, done_cv;
+  std::vector<Slice> slices;
+  size_t next = 0, left = 0;
+  bool stop = false;
+  void start(unsigned n) {
+    for (unsigned t = 0; t < n; t++)
+      th.emplace_back([this] {
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+          cv.wait(l, [&] { return stop || next < slices.size(); });
+          if (stop) return;
+          const Slice sl = slices[next++];
+          l.unlock();
+          memcpy(sl.dst, sl.src, sl.len);
+          l.lock();
+          if (--left == 0) done_cv.notify_all();
+        }
+      });
+  }
+  void add(std::vector<Slice>& v, void* dst, const void* src, size_t len) {
+    for (size_t o = 0; o < len; o += (size_t)1 << 20) v.push_back({static_cast<unsigned char*>(dst) + o, static_cast<const unsigned char*>(src) + o, std::min<size_t>((size_t)1 << 20, len - o)});
+  }
+  void run(std::vector<Slice>&& v) {     // returns when every slice is copied
+    if (v.empty()) return;
+    std::lock_guard<std::mutex> one(run_mu);
+    std::unique_lock<std::mutex> l(mu);
+    slices = std::move(v); next = 0; left = slices.size();
+    cv.notify_all();
+    done_cv.wait(l, [&] { return left == 0; });
+    slices.clear(); next = 0;
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> l(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+
+struct HostPipe {
+  static constexpr int NB = 3;
+  size_t chunk = 0;                      // ops per chunk
+  uint32_t* h_in[NB] = {nullptr, nullptr, nullptr};    // pinned: up to three arrays of `chunk` words
+  uint32_t* h_out[NB] = {nullptr, nullptr, nullptr};
+  uint32_t* d_in[NB] = {nullptr, nullptr, nullptr};
+  uint32_t* d_out[NB] = {nullptr, nullptr, nullptr};
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[NB], ev_k[NB];
+  CopyPool pool_in, pool_out;
+  HostPipe(size_t chunk_ops, unsigned t_in, unsigned t_out) : chunk(chunk_ops) {
+    for (int b = 0; b < NB; b++) {
+      HIP_OK(hipHostMalloc(&h_in[b], chunk * 12));
+      HIP_OK(hipHostMalloc(&h_out[b], chunk * 4));
+      dev_malloc(&d_in[b], chunk * 12);
+      dev_malloc(&d_out[b], chunk * 4);
+      HIP_OK(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&ev_k[b], hipEventDisableTiming));
+    }
+    HIP_OK(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    pool_in.start(t_in);
+    pool_out.start(t_out);
+  }
+  ~HostPipe() {
+    for (int b = 0; b < NB; b++) {
+      (void)hipHostFree(h_in[b]); (void)hipHostFree(h_out[b]); (void)hipFree(d_in[b]); (void)hipFree(d_out[b]);
+      (void)hipEventDestroy(ev_in[b]); (void)hipEventDestroy(ev_k[b]);
+    }
+    (void)hipStreamDestroy(s_in); (void)hipStreamDestroy(s_out);
+  }
+};
+
+size_t host_chunk_ops() {              // (read per call: tests set it per handle)
+  const char* a = getenv("SMATRIX_HOST_CHUNK_LG");
+  const unsigned lg = a ? (unsigned)std::min(26ul, std::max(12ul, strtoul(a, nullptr, 10))) : 21u;
+  return (size_t)1 << lg;
+}
+
+// n ops from up to three host arrays (in[q] == nullptr: not used), results (when `out`) to a host array; `compute` enqueues the
+// kernels of one chunk on the matrix's stream: compute(count, d_a0, d_a1, d_a2, d_out).  Caller holds m->mu.
+template <typename F>
+void host_pipeline(Matrix* m, size_t n, const uint32_t* const in[3], uint32_t* out, F compute) {
+  if (m->host_pipe && static_cast<HostPipe*>(m->host_pipe)->chunk != host_chunk_ops()) {
+    delete static_cast<HostPipe*>(m->host_pipe);
+    m->host_pipe = nullptr;
+  }
+  if (!m->host_pipe) {
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    m->host_pipe = new HostPipe(host_chunk_ops(), std::min(12u, hw / 2), std::min(8u, std::max(1u, hw / 4)));
+  }
+  HostPipe& hp = *static_cast<HostPipe*>(m->host_pipe);
+  const size_t C = hp.chunk, nc = (n + C - 1) / C;
+  const int dev = m->device;
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t fed = 0, computed = 0, drained = 0;       // chunks whose upload has been enqueued / whose kernels have been enqueued / returned
+  double t_feed_copy = 0, t_feed_wait = 0, t_drain_copy = 0, t_drain_dma = 0, t_main_wait = 0, t_main_compute = 0;   // (SMATRIX_TRACE_ROUNDS)
+  const double t_call = mono_s();
+  std::thread feeder([&] {
+    HIP_OK(hipSetDevice(dev));
+    for (size_t k = 0; k < nc; k++) {
+      const int b = (int)(k % HostPipe::NB);
+      const size_t cnt = std::min(C, n - k * C);
+      const double tf0 = mono_s();
+      if (k >= (size_t)HostPipe::NB) {
+        // the buffers of chunk k - NB: its kernels have been enqueued (they wait for nothing else that reads d_in) ... and have run
+        { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return computed >= k - HostPipe::NB + 1; }); }
+        HIP_OK(hipEventSynchronize(hp.ev_k[b]));
+      }
+      const double tf1 = mono_s();
+      std::vector<CopyPool::Slice> v;
+      for (int q = 0; q < 3; q++)
+        if (in[q]) hp.pool_in.add(v, hp.h_in[b] + (size_t)q * C, in[q] + k * C, cnt * 4);
+      hp.pool_in.run(std::move(v));
+      t_feed_wait += tf1 - tf0; t_feed_copy += mono_s() - tf1;
+      for (int q = 0; q < 3; q++)
+        if (in[q]) HIP_OK(hipMemcpyAsync(hp.d_in[b] + (size_t)q * C, hp.h_in[b] + (size_t)q * C, cnt * 4, hipMemcpyHostToDevice, hp.s_in));
+      HIP_OK(hipEventRecord(hp.ev_in[b], hp.s_in));
+      { std::lock_guard<std::mutex> l(mu); fed = k + 1; }
+      cv.notify_all();
+    }
+  });
+  std::thread drain;
+  if (out)
+    drain = std::thread([&] {
+      HIP_OK(hipSetDevice(dev));
+      for (size_t k = 0; k < nc; k++) {
+        const int b = (int)(k % HostPipe::NB);
+        const size_t cnt = std::min(C, n - k * C);
+        { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return computed >= k + 1; }); }
+        const double td0 = mono_s();
+        HIP_OK(hipStreamWaitEvent(hp.s_out, hp.ev_k[b], 0));
+        HIP_OK(hipMemcpyAsync(hp.h_out[b], hp.d_out[b], cnt * 4, hipMemcpyDeviceToHost, hp.s_out));
+        HIP_OK(hipStreamSynchronize(hp.s_out));
+        const double td1 = mono_s();
+        { std::lock_guard<std::mutex> l(mu); drained = k + 1; }       // (d_out of this set may be written again)
+        cv.notify_all();
+        std::vector<CopyPool::Slice> v;
+        hp.pool_out.add(v, out + k * C, hp.h_out[b], cnt * 4);
+        hp.pool_out.run(std::move(v));
+        t_drain_dma += td1 - td0; t_drain_copy += mono_s() - td1;
+      }
+    });
+  for (size_t k = 0; k < nc; k++) {
+    const int b = (int)(k % HostPipe::NB);
+    const size_t cnt = std::min(C, n - k * C);
+    const double tm0 = mono_s();
+    {
+      std::unique_lock<std::mutex> l(mu);
+      cv.wait(l, [&] { return fed >= k + 1 && (!out || k < (size_t)HostPipe::NB || drained >= k - HostPipe::NB + 1); });
+    }
+    const double tm1 = mono_s();
+    HIP_OK(hipStreamWaitEvent(m->stream, hp.ev_in[b], 0));
+    compute(cnt, hp.d_in[b], hp.d_in[b] + C, hp.d_in[b] + 2 * C, hp.d_out[b]);
+    HIP_OK(hipEventRecord(hp.ev_k[b], m->stream));
+    t_main_wait += tm1 - tm0; t_main_compute += mono_s() - tm1;
+    { std::lock_guard<std::mutex> l(mu); computed = k + 1; }
+    cv.notify_all();
+  }
+  feeder.join();
+  if (drain.joinable()) drain.join();
+  HIP_OK(hipStreamSynchronize(m->stream));
+  if (m->trace_rounds)
+    fprintf(stderr, "[smatrix] host pipeline: %zu ops in %zu chunks, %.2f ms | feeder: copies %.2f, waits %.2f | caller: waits %.2f, kernels %.2f | drain: device-to-host + waits %.2f, copies %.2f\n",
+            n, nc, (mono_s() - t_call) * 1e3, t_feed_copy * 1e3, t_feed_wait * 1e3, t_main_wait * 1e3, t_main_compute * 1e3, t_drain_dma * 1e3, t_drain_copy * 1e3);
+}
+
 // ---- C ABI -----------------------------------------------------------------------
 extern "C" {
 
@@ -2013,6 +2195,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_small) (void)hipHostFree(m->h_small);
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
+      delete static_cast<HostPipe*>(m->host_pipe);
       m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
@@ -2086,6 +2269,16 @@ int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, co
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = m->stream;
+  if (n >= 2 * host_chunk_ops() && (op == OP_GET || v)) {
+    // a large call: chunks through pinned memory, upload / kernels / return overlapped (host_pipeline)
+    const uint32_t* in[3] = {x, y, op != OP_GET ? v : nullptr};
+    m->no_ret = out == nullptr;
+    host_pipeline(m, n, in, out, [&](size_t cnt, uint32_t* dx, uint32_t* dy, uint32_t* dv, uint32_t* dout) {
+      apply_dev_locked(self, op, cnt, dx, dy, dv, dout, s);
+    });
+    m->no_ret = false;
+    return 0;
+  }
   m->sx.need(n); m->sy.need(n); m->so.need(n);
   HIP_OK(hipMemcpyAsync(m->sx.p, x, n * 4, hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(m->sy.p, y, n * 4, hipMemcpyHostToDevice, s));
@@ -2137,6 +2330,14 @@ int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t*
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
   hipStream_t s = m->stream;
+  if (n >= 2 * host_chunk_ops()) {
+    const uint32_t* in[3] = {x, nullptr, nullptr};
+    host_pipeline(m, n, in, out, [&](size_t cnt, uint32_t* dx, uint32_t*, uint32_t*, uint32_t* dout) {
+      hipLaunchKernelGGL(k_rowlen, dim3(blocks_for(cnt)), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, (uint32_t)cnt, dx, dout);
+      HIP_OK(hipGetLastError());
+    });
+    return 0;
+  }
   m->sx.need(n); m->so.need(n);
   HIP_OK(hipMemcpyAsync(m->sx.p, x, n * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_rowlen, dim3(blocks_for(n)), dim3(256), 0, s, m->d_dir, m->dir_size - 1,

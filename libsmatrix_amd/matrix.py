@@ -83,25 +83,28 @@ class SparseMatrix:
         return int(self._h.contents.mem)
 
     # ---- batched API --------------------------------------------------------
-    def apply_batch(self, op, x, y, v=None, results=True):
+    def apply_batch(self, op, x, y, v=None, results=True, out=None):
         """results=False: no result array is passed (include/smatrix_batch.h: the table ends in the same state, the
-        kernels skip the results) and None is returned"""
+        kernels skip the results) and None is returned; out: the caller's own result array (uint32, same length)"""
         x, y = _u32(x), _u32(y)
         assert x.shape == y.shape
-        out = np.empty_like(x) if results else None
+        if out is not None:
+            assert results and out.dtype == np.uint32 and out.shape == x.shape and out.flags["C_CONTIGUOUS"]
+        else:
+            out = np.empty_like(x) if results else None
         vv = _u32(v) if v is not None else None
         self._lib.smatrix_apply_batch(self._h, op, x.size, _p(x), _p(y),
                                       _p(vv) if vv is not None else None, _p(out) if results else None)
         return out
 
-    def get_batch(self, x, y):
-        return self.apply_batch(OP_GET, x, y)
+    def get_batch(self, x, y, out=None):
+        return self.apply_batch(OP_GET, x, y, out=out)
 
     def set_batch(self, x, y, v):
         return self.apply_batch(OP_SET, x, y, v)
 
-    def incr_batch(self, x, y, v):
-        return self.apply_batch(OP_INCR, x, y, v)
+    def incr_batch(self, x, y, v, out=None):
+        return self.apply_batch(OP_INCR, x, y, v, out=out)
 
     def decr_batch(self, x, y, v):
         return self.apply_batch(OP_DECR, x, y, v)

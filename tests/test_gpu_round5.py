@@ -222,3 +222,37 @@ def test_dense_zipf_stream_with_and_without_the_far_join(G, oracle_mod, monkeypa
         assert g.row_info(r) == o.row_info(r), r
     assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
     g.close(); o.close(); gen.close()
+
+
+# ---- the host-pointer batch API as a three-stage pipeline ------------------------------------------------------
+def test_large_host_batches_run_in_chunks_like_one_call(G, oracle_mod, monkeypatch):
+    """smatrix_apply_batch / smatrix_rowlen_batch with arrays above two chunks stage the caller's memory through pinned buffers
+    in chunks (here 2^14 ops, so that 10^5-op calls are seven chunks; default 2^21): upload, kernels and return of consecutive
+    chunks overlap on three streams.  A write batch's chunks are applied in order, so the call still behaves like ONE batch:
+    per-key return multisets of incr / decr, set with duplicates across chunk borders (the later op wins, src/smatrix.c:230 in
+    call order), gets, calls without a result array, rowlen -- all the oracle's; and the same calls with the pipeline out of reach
+    (chunk 2^26) give the same tables."""
+    rng = np.random.default_rng(99)
+    n = 100000 + 12345
+    x = (rng.zipf(1.2, n) % 3000).astype(np.uint32)
+    y = (rng.zipf(1.1, n) % 50000).astype(np.uint32) + 1
+    results = {}
+    for lg in ("14", "26"):
+        monkeypatch.setenv("SMATRIX_HOST_CHUNK_LG", lg)
+        g, o = G(), oracle_mod.Oracle()
+        v = ((x * 3 + y) % 5 + 1).astype(np.uint32)
+        kk = x.astype(np.uint64) << np.uint64(32) | y
+        for op in (2, 2, 3):
+            a, b = g.m.apply_batch(op, x, y, v), o.apply(op, x, y, v)
+            assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), (lg, op)
+        g.m.apply_batch(2, x, y, v, results=False); o.apply(2, x, y, v)           # no result array
+        sv = np.random.default_rng(7).integers(1, 1 << 30, n, dtype=np.uint32)    # set: duplicates far apart, the later op wins
+        a = g.m.set_batch(x, y, sv); o.apply(1, x, y, sv)
+        assert (a == sv).all()
+        got, want = g.m.get_batch(x, y), o.apply(0, x, y)
+        assert (got == want).all(), lg
+        rows = np.arange(0, 3000, dtype=np.uint32).repeat(12)                     # rowlen of 36 000 rows: three chunks
+        assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows[::12]], np.uint32).repeat(12)).all()
+        results[lg] = (got.copy(), g.stats()["rows"])
+        g.close(); o.close()
+    assert (results["14"][0] == results["26"][0]).all() and results["14"][1] == results["26"][1]
