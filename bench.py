@@ -67,7 +67,7 @@ def short_line(full, detail_path=None):
     line = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data")
     cfg = full.get("config", {})
-    c = _pick(cfg, "ids_per_axis", "batch_ops", "parallelism", "router")
+    c = _pick(cfg, "ids_per_axis", "batch_ops", "parallelism", "router", "rccl")
     c["workload"] = cfg.get("workload_short") or cfg.get("workload", "")[:200]
     if isinstance(cfg.get("placement"), dict):
         c["placement"] = _pick(cfg["placement"], "rows_placed_by_load", "ops_applied_over_mean")
@@ -299,8 +299,9 @@ def kernel_source_sha16():
     """identifies the kernels a PMC profile was taken with (profiles/*_pmc.json carries the same hash)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("smx_kernels.hpp", "smx_runtime.hip"):
-        h.update(open(os.path.join(ROOT, "libsmatrix_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "libsmatrix_amd", "csrc")
+    for f in ["smx_kernels.hpp"] + sorted(os.path.join("kernels", k) for k in os.listdir(os.path.join(csrc, "kernels")) if k.endswith(".hpp")) + ["smx_runtime.hip"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -796,6 +797,19 @@ def batch_size_leg(torch, dev, lg, stream):
     return {"batch_lg": lg, "steps": n, "ms_per_step": dt / n * 1e3, "ms_per_2^24_ops_step": dt / n * 1e3 / (B >> 24),
             "Mops_per_s": 2 * B * n / dt / 1e6, "rounds": int(st["rounds"]), "sanity": ok,
             "note": "NOT `value` (that stays at 2^24-op batches, comparable across rounds): the same stream in %d batches of 2^%d ops" % (nb, lg)}
+
+
+def rccl_library_in_use():
+    """{path, version} of the RCCL the C router binds in this process (include/smatrix_shard.h smatrix_shard_rccl_library: the copy
+    the process already holds -- torch's -- comes first, so that a torch process never ends up with two RCCLs on two HIP runtimes)"""
+    import ctypes as C
+    from libsmatrix_amd import _lib
+    lib = _lib.load()
+    lib.smatrix_shard_rccl_library.restype = C.c_char_p
+    lib.smatrix_shard_rccl_library.argtypes = [C.POINTER(C.c_int)]
+    v = C.c_int(0)
+    p = lib.smatrix_shard_rccl_library(C.byref(v))
+    return {"path": p.decode() if p else None, "version": v.value}
 
 
 def host_api_leg(B, calls=3):
@@ -1299,6 +1313,7 @@ def main():
     }
     if sharded:
         res["config"]["router"] = ("c-library/%s" % m.transport) if args.c_router else "torch.distributed/%s" % args.backend
+        res["config"]["rccl"] = rccl_library_in_use()            # which RCCL served the exchange: path and ncclGetVersion()
         if router_note:
             res["config"]["router_note"] = router_note
     if shard_info:

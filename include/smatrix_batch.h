@@ -173,7 +173,11 @@ int smatrix_flush(smatrix_t* self);
  * src/smatrix.c:430-436, and so do this library's -- same format, same leak): rewrites the backing file without those
  * blocks, all rows into a new file next to it, fsync, rename over the old one.  Needs room for a second copy while it
  * runs.  SMATRIX_COMPACT_AT_CLOSE=1 does it at close.  Not part of the drop-in surface; may change.  Returns 0. */
+#ifdef SMATRIX_EXPERIMENTAL
+/* (only for callers that define SMATRIX_EXPERIMENTAL, and only active in a process run with SMATRIX_EXPERIMENTAL=1 in its
+ *  environment: otherwise the call prints a note, leaves the file alone and returns -1) */
 int smatrix_compact(smatrix_t* self);
+#endif
 /* on: time every round-0 op kernel with HIP events on its stream (adds one sync per
  * batch); resets the kernel_* accumulators.  Also enabled by SMATRIX_PROFILE=1. */
 void smatrix_profile(smatrix_t* self, int on);

@@ -97,6 +97,10 @@ int smatrix_shard_rank(smatrix_shard_t* sh);
 int smatrix_shard_nranks(smatrix_shard_t* sh);
 uint64_t smatrix_shard_ops_applied(smatrix_shard_t* sh);        /* ops this rank's shard has applied (load balance) */
 const char* smatrix_shard_transport(smatrix_shard_t* sh);       /* "self" (one rank), "rccl", "shm" */
+/* The RCCL the router uses in this process: the path it is mapped from and ncclGetVersion() (e.g. 22203).  The copy the
+ * process already holds wins (a torch process: torch's own librccl), else SMATRIX_RCCL_LIB, librccl.so.1, librccl.so.
+ * NULL when no RCCL can be loaded.  Needs no GPU and no open shard. */
+const char* smatrix_shard_rccl_library(int* version);
 
 /* a placement chosen by the caller instead (see PLACEMENT above), identical on every rank, before the first batch:
  * cuts: nranks-1 host words or NULL; place_pairs: place_slots x {x, owner+1} host words (open addressing as above) */

@@ -29,6 +29,7 @@
 #include <map>
 #include <vector>
 
+#define SMATRIX_EXPERIMENTAL 1
 #include "../../include/smatrix_batch.h"
 #include "../../include/smatrix_shard.h"
 #include "../../include/smx_probe.h"
@@ -2029,6 +2030,13 @@ int smatrix_flush(smatrix_t* self) {
 // include/smatrix_batch.h: the backing file rewritten without leaked blocks (no-op in memory mode)
 int smatrix_compact(smatrix_t* self) {
   Matrix* m = M(self);
+  // EXPERIMENTAL and outside the drop-in surface (the reference has no counterpart: its files only grow, src/smatrix.c:430-436):
+  // the prototype sits behind SMATRIX_EXPERIMENTAL in the header, and the call does nothing unless the process asks for it
+  const char* ex = getenv("SMATRIX_EXPERIMENTAL");
+  if (!ex || *ex != '1') {
+    fprintf(stderr, "libsmatrix: smatrix_compact is experimental; set SMATRIX_EXPERIMENTAL=1 to use it (nothing done)\n");
+    return -1;
+  }
   if (m->fname.empty() || !self->fd) return 0;
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
@@ -2130,7 +2138,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_BULK_MIN")) m->fix_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_BULK_SHARE")) m->fix_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_FSYNC")) m->file_fsync = *a == '1';
-  if (const char* a = getenv("SMATRIX_COMPACT_AT_CLOSE")) m->compact_at_close = *a == '1';
+  if (const char* a = getenv("SMATRIX_COMPACT_AT_CLOSE")) m->compact_at_close = *a == '1' && getenv("SMATRIX_EXPERIMENTAL") && *getenv("SMATRIX_EXPERIMENTAL") == '1';
   if (const char* a = getenv("SMATRIX_FLUSH_EVERY")) m->flush_every = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_FLUSH_MS")) m->flush_ms = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);

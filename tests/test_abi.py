@@ -72,3 +72,35 @@ def test_headers_and_c_caller_compile_as_c99(built, tmp_path):
     exe = str(tmp_path / "abi_known_answers")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + inc, os.path.join(ROOT, "tests", "c", "abi_known_answers.c"),
                     os.path.join(built, "smatrix.so"), "-Wl,-rpath," + built, "-o", exe], check=True)
+
+
+def test_router_binds_the_rccl_the_process_already_holds():
+    """VERDICT r4 #7a: the C router binds RCCL at run time; a process that already has one mapped -- a torch process has torch's
+    own librccl, on torch's HIP runtime -- must get THAT copy, not a second one from /opt/rocm (two RCCLs on two runtimes in one
+    process).  Two fresh interpreters: without torch the loader's librccl.so.1 is taken; after `import torch` the path under
+    torch/lib is.  No GPU needed: the library is only mapped and asked for its version."""
+    import subprocess
+    import sys
+    code = "\n".join([
+        "import ctypes as C, sys",
+        "%s",
+        "lib = C.CDLL(%r)",
+        "lib.smatrix_shard_rccl_library.restype = C.c_char_p",
+        "v = C.c_int(0)",
+        "p = lib.smatrix_shard_rccl_library(C.byref(v))",
+        "mapped = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l})",
+        "print(p.decode() if p else None, v.value, len(mapped))"])
+    so = os.path.join(ROOT, "libsmatrix_amd", "lib", "smatrix.so")
+    plain = subprocess.run([sys.executable, "-c", code % ("", so)], capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    path, version, n_mapped = plain.stdout.split()
+    if path == "None":
+        pytest.skip("no RCCL on this box")
+    assert int(version) > 20000 and int(n_mapped) == 1
+    with_torch = subprocess.run([sys.executable, "-c", code % ("import torch", so)], capture_output=True, text=True, timeout=600)
+    assert with_torch.returncode == 0, with_torch.stderr[-2000:]
+    tpath, tversion, tn_mapped = with_torch.stdout.split()
+    torch_copy = any("librccl" in f for f in os.listdir(os.path.join(os.path.dirname(__import__("torch").__file__), "lib")))
+    if torch_copy:
+        assert "/torch/lib/" in tpath, (tpath, path)           # torch's copy, not a second one
+    assert int(tn_mapped) == 1, "two RCCL copies mapped in one process"

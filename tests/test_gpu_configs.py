@@ -309,6 +309,7 @@ def test_incremental_flush_writes_dirty_rows_only(G, oracle_mod, tmp_path, monke
     back by the oracle (and by the compiled reference where present) and by this library's own loader."""
     import shutil
     monkeypatch.setenv("SMATRIX_FLUSH_MS", "0")              # explicit flushes only: the counts below are exact
+    monkeypatch.setenv("SMATRIX_EXPERIMENTAL", "1")          # smatrix_compact (no reference counterpart) is used at the end
     rng = np.random.default_rng(17)
     path = str(tmp_path / "inc.smx")
     g, o = G(path), oracle_mod.Oracle()

@@ -9,8 +9,9 @@ RND = "r04"
 
 def kernel_source_sha16():
     h = hashlib.sha256()
-    for f in ("smx_kernels.hpp", "smx_runtime.hip"):
-        h.update(open(os.path.join(ROOT, "libsmatrix_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "libsmatrix_amd", "csrc")
+    for f in ["smx_kernels.hpp"] + sorted(os.path.join("kernels", k) for k in os.listdir(os.path.join(csrc, "kernels")) if k.endswith(".hpp")) + ["smx_runtime.hip"]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
