@@ -103,6 +103,7 @@ def short_line(full, detail_path=None):
     summ = {"sustained_ms_per_step_median_group": g(full, "sustained", "ms_per_step_median_group"),
             "matches_reference_checksums": g(full, "reference_checksums", "matches_reference"),
             "dense_ids_Mops_per_s": g(full, "dense_ids", "Mops_per_s"),
+            "roofline_dense": _pick(g(full, "dense_ids", "roofline_dense") or {}, "kernel", "avg_launch_ms", "traffic", "r04_fetch_bytes", "achieved", "frac"),
             "op_kinds_Gops_per_s": g(full, "op_kinds", "Gops_per_s"),
             "host_api_Gops": {"incr": g(full, "host_api", "incr_Gops_per_s"), "get": g(full, "host_api", "get_Gops_per_s")},
             "config3": {"getrow_ms": g(full, "config3_getrow", "getrow_ms"), "frac": g(full, "config3_getrow", "roofline", "frac"),
@@ -860,7 +861,20 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
     ok = bool((o2 >= 1).all().item()) and int(st["rows"]) <= N_IDS
     m.close(); gen.close()
     n = steps - warm
-    return {"steps": n, "ms_per_step": dt / n * 1e3, "Mops_per_s": 2 * B * n / dt / 1e6, "rows": int(st["rows"]),
+    # the pass in front of prep (the dense stream's own kernel): time and HBM bytes per launch from the committed rocprofv3 passes of
+    # this same stream (tools/refresh_dense_profile.sh), only while they were taken with the kernels that are running
+    rd = None
+    try:
+        pd = json.load(open(os.path.join(ROOT, "profiles", "pmc_dense.json")))
+        if pd.get("kernel_source_sha16") == kernel_source_sha16():
+            rd = {"bound": "hbm", "kernel": pd["kernel"], "avg_launch_ms": pd["avg_launch_ms_last8"], "traffic": pd["fetch_bytes_per_launch"] + pd["write_bytes_per_launch"],
+                  "fetch_bytes": pd["fetch_bytes_per_launch"], "r04_fetch_bytes": pd["r04_walking_pass_fetch_bytes_per_launch"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "achieved": (pd["fetch_bytes_per_launch"] + pd["write_bytes_per_launch"]) / max(pd["avg_launch_ms_last8"], 1e-9) / 1e6,
+                  "source": pd["summary"]}
+            rd["frac"] = rd["achieved"] / HBM_PEAK_GBS
+    except Exception:
+        rd = None
+    return {"steps": n, "ms_per_step": dt / n * 1e3, "Mops_per_s": 2 * B * n / dt / 1e6, "rows": int(st["rows"]), "roofline_dense": rd,
             "incr_kernel_ms": st["kernel_ms_incr"] / max(st["kernel_launches_incr"], 1),
             "get_kernel_ms": st["kernel_ms_get"] / max(st["kernel_launches_get"], 1), "sanity": ok,
             "note": "same stream with id = rank (dense): row tables use the reference's identity hash y % size, so hot columns cluster"}
