@@ -52,7 +52,7 @@ hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- pytho
 # so the read misses of the incr kernel are TCC_MISS - TCC_EA0_ATOMIC; they include the streamed op arrays (12 B/op in = 3.1 M lines).
 #   k_apply_agg<INCR>: %.1f M read misses / %.1f G/s + %.1f M atomics / %.1f G/s = %.3f ms;  measured %.3f ms per launch (HIP events, growing table;
 #                      1.30 ms when every key is a hit) -> %.0f %% of that bound.  The atomics are 80 %% of it: one returning atomic per distinct key of a
-#                      2048-op tile (+ a ticket and a claim per new cell: tools/probe/tile_fold_census.py counts 15.0 M + 3.8 M + 3.8 M for batch 15) -- the LDS fold removes the duplicates inside a tile, not across tiles
+#                      2048-op tile (+ a ticket and a claim per new cell: the round-4 census counted 15.0 M + 3.8 M + 3.8 M for batch 15) -- the LDS fold removes the duplicates inside a tile, not across tiles
 #                      (how the kernel's time splits over these classes: profiles/r02_agg_kernel_phase_shares.txt).
 #   k_apply<GET>     : %.1f M misses / %.1f G/s = %.3f ms;  measured %.3f ms -> %.0f %%
 #   i.e. the kernels run within 15-30 %% of the chip's random-transaction rates for what they touch; the rest of the gap to the byte roofline is the COUNT
@@ -155,7 +155,7 @@ lines_f = [
  "measured: %.3f ms per step over the timed steps (%.2f G mixed ops/s); all-hit replay %.3f ms" % (b["ms_per_step"], b["value"] / 1e3, steady.get("ms_per_step", float("nan"))),
  "target of north_star: 0.40 of read8 = %.3f ms per step" % (2 * N / (0.4 * R * 1e9) * 1e3),
  "",
- "What the counts are made of (tools/probe/insert_census.py + tile_fold_census.py, batch 15 of the stream, CPU):",
+ "What the counts are made of (round 4 census of batch 15 of the stream on the CPU; the probes are in the git history):",
  "  14.99 M (tile, key) entries for 7.01 M distinct keys: one verify load + one returning atomic each; 3.74 M of them are inserts",
  "  (+ one `used` ticket each, + the claim CAS instead of the add).  95.6 % of the entries have ONE op in their tile (85 % of the ops):",
  "  the LDS fold removes the hot cells' serialisation, not transactions.  6.07 M of the 7.01 M keys appear in one tile only; the 0.94 M",
