@@ -165,7 +165,10 @@ __device__ inline uint32_t select_bit(unsigned long long w, uint32_t r) {
 // estimates from the batch before) is simply not in F and takes the wave-cooperative walk as before.  Off once a probe chain
 // may have been cut (ArenaHead::twins: a key may then sit twice and the scan cannot know which cell a probe finds first).
 constexpr uint32_t FAR_UNIT_LG = 9;                       // rows are scanned in units of 512 cells (8 occupancy words)
-constexpr uint32_t FAR_ROW_LG = 9;                        // ... from 512 cells up (long probes start in rows of a few hundred cells)
+#ifndef SMX_FAR_ROW_LG
+#define SMX_FAR_ROW_LG 13
+#endif
+constexpr uint32_t FAR_ROW_LG = SMX_FAR_ROW_LG;           // ... of rows from 8192 cells up: measured 9..18 on the dense-id stream (10.7 / 10.4 / 10.2 / 10.1 / 10.1 ms at 9 / 11 / 12 / 13 / 14, 10.3 at 16, 11.8 at 18)
 constexpr uint32_t FAR_UNIT_WORDS = 1u << (FAR_UNIT_LG - 6);
 constexpr uint32_t FAR_NOT_FOUND = 0xFFFFFFFFu;
 __device__ inline uint32_t far_hash(uint32_t base, uint32_t Y) { return fmix32(base * 0x9E3779B1u + Y * 0x85EBCA77u + 0x27d4eb2fu); }
@@ -1047,12 +1050,13 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
     V[k] = vs[(size_t)j[k] * ST];
     const uint64_t key = (uint64_t)X | ((uint64_t)Y << 32);
     if (key == ~0ull) { slot[k] = ~0u - 1; continue; }      // the LDS table's empty marker: per-op path
-    uint32_t h = (X * 0x9E3779B1u) ^ (Y * 0x85EBCA77u);
-    h = (h ^ (h >> 15)) & (AGG_SLOTS - 1);
+    // CLU: the 16 cells of one 128-byte line of a row take 16 consecutive slots, and the list below is in slot order (see there)
+    uint32_t h = (X * 0x9E3779B1u) ^ ((CLU ? Y >> 4 : Y) * 0x85EBCA77u);
+    h = ((h ^ (h >> 15)) + (CLU ? Y & 15u : 0u)) & (AGG_SLOTS - 1);
     for (;;) {
       uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&l_key[h]), ~0ull,
                                 (unsigned long long)key);
-      if (prev == ~0ull) l_list[atomicAdd(&l_n, 1u)] = (uint16_t)h;     // first of its key
+      if (!CLU && prev == ~0ull) l_list[atomicAdd(&l_n, 1u)] = (uint16_t)h;     // first of its key
       if (prev == ~0ull || prev == key) break;
       h = (h + 1) & (AGG_SLOTS - 1);
     }
@@ -1060,6 +1064,32 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
     slot[k] = h;
   }
   __syncthreads();
+  if constexpr (CLU) {
+    // (round 5) Dense ids put the hottest cells of a hot row side by side: the 16 hottest cells of the hottest row are ONE 128-byte
+    // line, and every tile adds to each of them.  Returning atomics on one line are served one REQUEST at a time (tools/probe/
+    // atomic_line.hip: 5.7 ns per request from lanes of different waves, 11 ns for a whole wave instruction whose 16 lanes hit 16
+    // cells of the line): with the keys in arrival order a tile sent 16 requests to that line, 1.3 x 10^5 per batch, and the kernel
+    // took 2.9 ms against 1.7 without its atomics.  In slot order the keys of a line sit in adjacent lanes of phase 2 -- one
+    // request per tile and line for the cell loads and for the atomics.
+    __shared__ uint32_t l_wave[AGG_THREADS / 64];
+    constexpr uint32_t PER = AGG_SLOTS / AGG_THREADS;
+    uint32_t occ = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) occ |= (l_key[tid * PER + q] != ~0ull ? 1u : 0u) << q;
+    uint32_t incl = (uint32_t)__popc(occ);
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+      if ((tid & 63u) >= d) incl += o;
+    }
+    if ((tid & 63u) == 63u) l_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t at = incl - (uint32_t)__popc(occ);
+    for (uint32_t w = 0; w < (tid >> 6); w++) at += l_wave[w];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) if (occ & (1u << q)) l_list[at++] = (uint16_t)(tid * PER + q);
+    if (tid == AGG_THREADS - 1) l_n = at;
+    __syncthreads();
+  }
   // phase 2: a lane owns up to AGG_OPT distinct keys.  The common case -- directory hit on the
   // first probe, cell hit on the first probe -- is software-pipelined over the lane's keys (all
   // directory loads in flight, then all cell loads, then all atomics) so that the three dependent
