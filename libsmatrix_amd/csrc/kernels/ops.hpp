@@ -98,6 +98,10 @@ struct ArenaHead {
   const uint32_t* far_zeros;                  // free cells per unit (at the scan): a probe steps over units without any
   uint32_t far_overflow;                      // a far key did not fit the table in this batch: no claimed inserts (k_far_keys, far_claim_insert)
   unsigned long long* dbg;                    // measurement runs only (SMATRIX_REST_DBG): event counters, see smatrix_close
+  // claimed inserts by RANK (far_claim_insert): the occupancy words as the scan left them, and per word how many of its free
+  // cells have been handed out -- parallel to far_occ
+  const unsigned long long* far_occ0;
+  uint32_t* far_clm;
 };
 static_assert(sizeof(ArenaHead) <= 128, "unit 0 of the arena");
 #ifndef SMX_HINT_BUDGET
@@ -288,31 +292,56 @@ __device__ inline uint32_t far_claim_insert(DirSlot* d, const uint4 s, uint8_t* 
   }
   const uint32_t first = OP == OP_DECR ? 0u - V : V;
   const uint32_t nwords = (mask + 1u) >> 6, wmask = nwords - 1u;
+  // (round 5) Which free cell of a word a claimer gets is decided by RANK: one fetch-add on the word's counter, and the r-th
+  // claimer owns the r-th cell that was free at the scan (far_occ0) -- one atomic per claimer and word, winners in first-free
+  // order.  Going for the lowest clear bit with the atomic OR alone made every claimer of a word try the SAME bit: one winner per
+  // round trip, up to 64 round trips per word and claimer.  The new keys of a young dense-id table's hottest rows made 13 attempts
+  // on average and 827 at most, each queued behind hundreds of others on one address: single ops of 3-4 ms, which the whole pass
+  // waited for.  The first word of a claimer whose front is not that word's first free cell -- the cells below belong to the keys
+  // of an earlier run -- keeps the OR protocol, on the bits from its front up: a rank naming a cell the claimer may not take
+  // would leave that cell empty for good.  The OR still marks every claimed cell in the live words (the probes read them).
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  const unsigned long long* occ0 = ah->far_occ0 + (occ - ah->far_occ);
+  uint32_t* clm = ah->far_clm + (occ - ah->far_occ);
   uint32_t w = e0 >> 6;
-  unsigned long long z = ~__hip_atomic_load(&occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (~0ull << (e0 & 63u));
+  unsigned long long from = ~0ull << (e0 & 63u);     // (the first word counts from the front's bit only)
   for (uint32_t walked = 0; walked <= nwords + FAR_UNIT_WORDS;) {
-    if (z) {
-      const uint32_t b = (uint32_t)__ffsll(z) - 1u;
-      const unsigned long long bit = 1ull << b;
-      const unsigned long long old = atomicOr(&occ[w], bit);
-      z &= ~(old | bit);                              // (what the word really held: the bits others have set since are not tried)
-      if (old & bit) continue;                        // somebody else's
-      const uint32_t pos = (w << 6) + b;
-      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull, (unsigned long long)pack_cell(Y, first));
-      if (prev == 0) { *where = pos; return first; }
-      if (cell_key(prev) == Y) {                      // (not with one op per key; kept for safety: the cell is updated, the ticket goes back)
-        atomicSub(ticket, 1u);
-        uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
-        *where = pos;
-        return OP == OP_INCR ? atomicAdd(vp, V) + V : atomicSub(vp, V) - V;
+    unsigned long long z = ~__hip_atomic_load(&occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & from;
+    const unsigned long long z0 = ~occ0[w];
+    const bool by_or = (z0 & ~from) != 0;
+    const uint32_t nfree0 = (uint32_t)__popcll(z0);
+    if (z && (by_or || __hip_atomic_load(&clm[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfree0)) {
+      for (;;) {
+        uint32_t b;
+        if (by_or) {
+          if (!z) break;
+          b = (uint32_t)__ffsll(z) - 1u;
+        } else {
+          const uint32_t rk = atomicAdd(&clm[w], 1u);
+          if (rk >= nfree0) break;                    // every cell of this word that was free at the scan has its claimer
+          b = select_bit(z0, rk);
+        }
+        const unsigned long long bit = 1ull << b;
+        const unsigned long long old = atomicOr(&occ[w], bit);
+        z &= ~(old | bit);                            // (what the word really held: the bits others have set since are not tried)
+        if (old & bit) continue;                      // somebody else's (a claimer by OR)
+        const uint32_t pos = (w << 6) + b;
+        const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull, (unsigned long long)pack_cell(Y, first));
+        if (prev == 0) { *where = pos; return first; }
+        if (cell_key(prev) == Y) {                    // (not with one op per key; kept for safety: the cell is updated, the ticket goes back)
+          atomicSub(ticket, 1u);
+          uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
+          *where = pos;
+          return OP == OP_INCR ? atomicAdd(vp, V) + V : atomicSub(vp, V) - V;
+        }
+        // a plain insert took the cell meanwhile (or it holds the row's (0, v) entry): the claim stands for it, on
       }
-      continue;                                       // a plain insert took the cell meanwhile: the claim stands for it, on
     }
+    from = ~0ull;
     w = (w + 1) & wmask;
     walked++;
     if ((w & (FAR_UNIT_WORDS - 1u)) == 0)             // units without a free cell at the scan are full for good
       while (walked <= nwords + FAR_UNIT_WORDS && zeros[w >> (FAR_UNIT_LG - 6)] == 0) { w = (w + FAR_UNIT_WORDS) & wmask; walked += FAR_UNIT_WORDS; }
-    z = ~__hip_atomic_load(&occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   atomicSub(ticket, 1u);
   *deferred = true;
@@ -646,7 +675,7 @@ __device__ __forceinline__ void apply_body(
         const long long hf0 = hdbg ? clock64() : 0;
         const FarHit fh = far_find(arena, lp.cells, Y);
         if (hdbg) h_find = clock64() - hf0;
-        if (ah->dbg && !hdbg) atomicAdd(&ah->dbg[16 + fh.state], 1ull);
+        if (ah->dbg && !hdbg && (t & 63u) == 0) atomicAdd(&ah->dbg[16 + fh.state], 64ull);
         if (fh.state == FAR_FOUND) {
           if (has_hints) was_long = ((fh.slot - Y) & lp.mask) > PROBE_BUDGET;
           lp.need = false;
@@ -697,8 +726,12 @@ __device__ __forceinline__ void apply_body(
         if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; was_long = true; }   // neither the key nor an empty cell: prep grows the row
         else {
           if (has_hints) was_long = ((p - Y) & lp.mask) > PROBE_BUDGET;
-          if (OP != OP_GET && OP != OP_SET && ranked && ld_relaxed(&lp.cells[p]) == 0) {
-            // the first cell that was free at the scan is still free: the key goes in by rank from this front
+          if (OP != OP_GET && OP != OP_SET && ranked) {
+            // the first cell that was free at the scan -- free still, or taken since (by a claim the probe's copy of the word did
+            // not show yet, or by a plain insert): either way this key, absent at the scan and inserted by this op alone, goes
+            // into the first cell it can CLAIM from here on.  (Round 5: a taken cell used to send the op back to the lane's own
+            // walk, 48 dependent loads, then to another cooperative probe: the latest of thousands of new keys behind one run
+            // took a hundred such turns -- single trips of 3-4 ms, which the whole pass waited for.)
             ranked = false;
             uint32_t where = p;
             r = far_claim_insert<OP == OP_DECR ? OP_DECR : OP_INCR>(d, s, arena, Y, V, p, const_cast<unsigned long long*>(occ), zer, const_cast<uint64_t*>(lp.cells), lp.mask, &deferred, &where);
@@ -726,7 +759,15 @@ __device__ __forceinline__ void apply_body(
     }
     if (tdbg) {
       tc3 = clock64();
-      if (__lane_id() == 0 && live) {
+      if (__lane_id() == 0 && live && tc3 - tc0 > 100000) {   // the long trips: how many, the longest, by row size (2^(4k..)), how it ended
+        atomicAdd(&tdbg[28], 1ull); atomicMax(&tdbg[29], (unsigned long long)(tc3 - tc0)); atomicAdd(&tdbg[30], (unsigned long long)(tc3 - tc0));
+        atomicAdd(&tdbg[32 + min(meta_lg(s.x) / 4u, 5u)], 1ull);
+        atomicAdd(&tdbg[38 + (deferred ? 1 : 0)], 1ull);
+        atomicMax(&tdbg[31], (unsigned long long)t_coop);
+        atomicAdd(&tdbg[40], (unsigned long long)(tc1 - tc0)); atomicAdd(&tdbg[41], (unsigned long long)(tc2 - tc1)); atomicAdd(&tdbg[42], (unsigned long long)t_coop);
+        atomicAdd(&tdbg[43], (unsigned long long)(tc3 - tc2 - t_coop));
+      }
+      if (__lane_id() == 0 && live && (t & 63u) == 0) {      // (one op in 64: the counters' own atomics must not be what is measured)
         atomicAdd(&tdbg[20], (unsigned long long)(tc1 - tc0)); atomicAdd(&tdbg[21], (unsigned long long)(tc2 - tc1));
         atomicAdd(&tdbg[22], (unsigned long long)t_coop); atomicAdd(&tdbg[23], (unsigned long long)(tc3 - tc2 - t_coop)); atomicAdd(&tdbg[24], 1ull);
       }
@@ -960,8 +1001,15 @@ __global__ __launch_bounds__(256) void k_apply_far(
 
 // ... and the same a wave per op (measured faster: 2.6 against 3.5-4.6 ms per dense-id batch -- a wave with 64 far ops still
 // takes their cooperative walks one after the other)
+#ifndef SMX_WPO_FAR_WAVES
+#define SMX_WPO_FAR_WAVES 5     /* 96 VGPRs = 5 waves per SIMD: the pass is bound by the latency of its dependent loads (4 waves 1.80 ms, 5 waves 1.52 ms, 6 waves with spills 1.82 ms) */
+#endif
 template <int OP>
-__global__ __launch_bounds__(256) void k_apply_wpo_far(
+__global__ __launch_bounds__(256)
+#if SMX_WPO_FAR_WAVES
+__attribute__((amdgpu_waves_per_eu(SMX_WPO_FAR_WAVES, SMX_WPO_FAR_WAVES)))
+#endif
+void k_apply_wpo_far(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
@@ -1440,7 +1488,7 @@ __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32
 // k_far_scan: a wave per unit: the occupancy words (a (0, v) cell counts as free: it may turn back into an empty one, quirk Q1),
 // the unit's count of free cells, and every displaced cell's slot into its key's entry of F, if it has one.
 __global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot* dir, const uint32_t* unit_row, uint32_t cap_units, uint8_t* arena,
-                                                  uint4* tab, uint32_t tmask, unsigned long long* occ, uint32_t* zeros) {
+                                                  uint4* tab, uint32_t tmask, unsigned long long* occ, uint32_t* zeros, unsigned long long* occ0, uint32_t* clm) {
   const uint32_t n_units = min(aload(&ctl->n_units), cap_units);
   const uint32_t lane = threadIdx.x & 63u, nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < n_units; u += nwaves) {     // (wave-uniform)
@@ -1460,7 +1508,7 @@ __global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot*
       const bool taken = c[q] != 0 && key != 0;
       const uint64_t m = __ballot(taken);
       free_cells += 64u - (uint32_t)__popcll(m);
-      if (lane == 0) occ[(size_t)u * FAR_UNIT_WORDS + q] = m;
+      if (lane == 0) { occ[(size_t)u * FAR_UNIT_WORDS + q] = m; occ0[(size_t)u * FAR_UNIT_WORDS + q] = m; clm[(size_t)u * FAR_UNIT_WORDS + q] = 0; }
       if (taken && (key & mask) != p) {
         uint4* e = far_entry(tab, tmask, d.base, key);
         if (e) e->z = p;

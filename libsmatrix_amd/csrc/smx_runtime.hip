@@ -673,7 +673,8 @@ struct Matrix {
                                         // words itself -- slower (4.0 against 2.8 ms per dense-id batch: a wave's trip takes as long as its slowest lane)
   DevBuf<uint4> far_tab;
   DevBuf<uint32_t> far_unit_row, far_zeros;
-  DevBuf<unsigned long long> far_occ;
+  DevBuf<unsigned long long> far_occ, far_occ0;
+  DevBuf<uint32_t> far_clm;
   uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
   uint32_t far_nd_seen = 0;             // ops in the list the last join was built for
   uint32_t far_rows_seen = 0, far_units_seen = 0;   // rows of >= 2^HOME_LG cells / their 1024-cell units when they were last counted
@@ -852,11 +853,15 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
   m->far_unit_row.need(cap_units);
   const bool moved = m->far_tab.cap < ((size_t)1 << lg) || m->far_occ.cap < (size_t)cap_units * FAR_UNIT_WORDS || m->far_zeros.cap < cap_units;
   m->far_tab.need((size_t)1 << lg); m->far_occ.need((size_t)cap_units * FAR_UNIT_WORDS); m->far_zeros.need(cap_units);
+  m->far_occ0.need((size_t)cap_units * FAR_UNIT_WORDS); m->far_clm.need((size_t)cap_units * FAR_UNIT_WORDS);      // (they move with far_occ)
   if (moved || m->far_tab_lg != lg) {
     struct { uint32_t mask; uint4* tab; const unsigned long long* occ; const uint32_t* zeros; } __attribute__((packed)) w = {(1u << lg) - 1u, m->far_tab.p, m->far_occ.p, m->far_zeros.p};
     static_assert(sizeof(w) == 28 && offsetof(ArenaHead, far_tab) == offsetof(ArenaHead, far_mask) + 4 && offsetof(ArenaHead, far_occ) == offsetof(ArenaHead, far_tab) + 8 &&
                   offsetof(ArenaHead, far_zeros) == offsetof(ArenaHead, far_occ) + 8, "ArenaHead layout");
     HIP_OK(hipMemcpyAsync(m->arena.base + offsetof(ArenaHead, far_mask), &w, sizeof(w), hipMemcpyHostToDevice, s));
+    struct { const unsigned long long* occ0; uint32_t* clm; } w2 = {m->far_occ0.p, m->far_clm.p};
+    static_assert(sizeof(w2) == 16 && offsetof(ArenaHead, far_clm) == offsetof(ArenaHead, far_occ0) + 8, "ArenaHead layout");
+    HIP_OK(hipMemcpyAsync(m->arena.base + offsetof(ArenaHead, far_occ0), &w2, sizeof(w2), hipMemcpyHostToDevice, s));
     HIP_OK(hipStreamSynchronize(s));                       // (`w` is on the stack; rare: the buffers moved)
     m->far_tab_lg = lg;
   }
@@ -871,7 +876,7 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
                      m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u);
   DBG_STEP(m, s, "k_far_keys");
   hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 32768)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_unit_row.p, cap_units,
-                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p);
+                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p);
   DBG_STEP(m, s, "k_far_scan");
   HIP_OK(hipGetLastError());
   arena_head_set(m, offsetof(ArenaHead, far_on), 1u, s);
@@ -1472,9 +1477,20 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       uint32_t* dlp = m->defer[1].p;
       hipLaunchKernelGGL(k_round_advance, dim3(1), dim3(64), 0, s, m->d_ctl, m->rebal.p, m->d_dir, m->arena.base);
       // (the table is sized from the list the last join saw -- the folding kernel's deferred ops, 2-4x what the pass leaves)
-      far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(std::max<uint64_t>({2ull * m->spec_nd_prev, 3ull * m->far_nd_seen / 2, 1ull << 16}), cur_n));
+      // (a round the host drives anyway: the list's length is read instead -- the first joins of a young table, whose lists are the
+      //  longest, ran with a table sized for 2^16 keys and overflowed: 9 ms for the pass of the dense stream's third batch)
+      uint64_t est_far = std::max<uint64_t>({2ull * m->spec_nd_prev, 3ull * m->far_nd_seen / 2, 1ull << 16});
+      if (!chained && m->far_join && m->home_on) {
+        uint32_t nd_now = 0;
+        HIP_OK(hipMemcpyAsync(&nd_now, &m->d_ctl->n_prev, 4, hipMemcpyDeviceToHost, s));      // (k_round_advance has just moved it there)
+        HIP_OK(hipStreamSynchronize(s));
+        est_far = (uint64_t)nd_now + nd_now / 8 + 1024;
+        if (m->trace_rounds) fprintf(stderr, "[smatrix] batch %llu: the folding kernel deferred %u ops\n", (unsigned long long)m->st.batches, nd_now);
+      }
+      far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(est_far, cur_n));
       if (far_joined && !m->far_lanes) {
-        const dim3 wgrid(65536);
+        static const uint32_t wg_env = getenv("SMATRIX_WPO_GRID") ? (uint32_t)strtoul(getenv("SMATRIX_WPO_GRID"), nullptr, 10) : 65536u;
+        const dim3 wgrid(wg_env);
         if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
         else hipLaunchKernelGGL((k_apply_wpo_far<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
       } else if (far_joined) {
@@ -1561,8 +1577,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         memcpy(last, now, sizeof last);
       }
       if (m->trace_rounds)
-        fprintf(stderr, "[smatrix] batch %llu chain: ops=%u deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u | long probes %u%s\n",
-                (unsigned long long)m->st.batches, cur_n, nd_chain0, c.spec_nt0, (unsigned long long)c.spec_gu0, c.spec_nrebal0,
+        fprintf(stderr, "[smatrix] batch %llu chain: ops=%u (the pass in front of prep took %u) deferred=%u grow=%u (%llu units) rebal=%u refused=%u | after the retry: deferred=%u grow=%u rows=%u | long probes %u%s\n",
+                (unsigned long long)m->st.batches, cur_n, far_joined ? c.far_nd : 0u, nd_chain0, c.spec_nt0, (unsigned long long)c.spec_gu0, c.spec_nrebal0,
                 c.spec_failed, c.n_defer, c.n_tasks, c.dir_used, c.n_long_ops, m->clustered ? " (clustered)" : "");
       // clustered mode goes off again after 8 chained batches in a row with hardly a long probe (the ids have changed their
       // nature: the wave-per-op pass in front of prep costs a scrambled-id batch 1.2 ms)
@@ -1578,9 +1594,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     } else if (pre_pass) {
       // the host-driven round 0 with the pass in front of prep: the list that is left sits in defer[1], so the next round is numbered 2
       if (far_joined) { m->far_rows_seen = m->h_ctl->n_big; m->far_units_seen = m->h_ctl->n_units; m->far_nd_seen = m->h_ctl->far_nd; }
-      if (m->trace_rounds)
-        fprintf(stderr, "[smatrix] batch %llu round 0 with the pass in front of prep: ops=%u deferred=%u grow=%u rows=%u\n", (unsigned long long)m->st.batches, cur_n,
-                m->h_ctl->n_defer, m->h_ctl->n_tasks, m->h_ctl->dir_used);
+      if (m->trace_rounds) {
+        uint32_t ovf = 0;
+        HIP_OK(hipMemcpy(&ovf, m->arena.base + offsetof(ArenaHead, far_overflow), 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smatrix] batch %llu round 0 with the pass in front of prep (it took %u ops; join table 2^%u%s): ops=%u deferred=%u grow=%u rows=%u\n", (unsigned long long)m->st.batches,
+                far_joined ? m->h_ctl->far_nd : 0u, m->far_tab_lg, ovf ? ", OVERFLOWED" : "", cur_n, m->h_ctl->n_defer, m->h_ctl->n_tasks, m->h_ctl->dir_used);
+      }
     } else if (m->trace_rounds) {
       static thread_local double t_prev = 0;
       struct timespec ts;
@@ -2171,11 +2190,15 @@ void smatrix_close(smatrix_t* self) {
       unsigned long long c[64];
       HIP_OK(hipMemcpy(c, m->rest_dbg, 512, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smatrix] far join, long probes of the wave-per-op pass: not in the table %llu, cell known %llu, absent at the scan %llu\n", c[16], c[17], c[18]);
-      if (c[40]) fprintf(stderr, "[smatrix] far_walk: %llu walks, %.0f cells on average, longest %llu; by row size 2^(4k..): %llu %llu %llu %llu %llu %llu\n", c[40], c[41] / (double)c[40], c[42],
+      if (c[40] && m->far_lanes) fprintf(stderr, "[smatrix] far_walk: %llu walks, %.0f cells on average, longest %llu; by row size 2^(4k..): %llu %llu %llu %llu %llu %llu\n", c[40], c[41] / (double)c[40], c[42],
                          c[43], c[44], c[45], c[46], c[47], c[48]);
       if (c[24]) fprintf(stderr, "[smatrix] (lane-per-op pass: per wave trip, longest lane: join look-up / walk / insert / whole trip; then the maxima of walk, insert, trip: %llu %llu %llu)\n", c[25], c[26], c[27]);
       if (c[24]) fprintf(stderr, "[smatrix] wave-per-op pass with the join, cycles per op: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f  (%llu ops)\n",
-                         c[20] / (double)c[24], c[21] / (double)c[24], c[22] / (double)c[24], c[23] / (double)c[24], c[24]);
+                         c[20] / (double)c[24], c[21] / (double)c[24], c[22] / (double)c[24], c[23] / (double)c[24], 64 * c[24]);
+      if (c[28]) fprintf(stderr, "[smatrix] wave-per-op pass with the join: %llu trips of more than 10^5 cycles (%.0f on average, the longest %llu, longest cooperative probe %llu); by row size 2^(4k..): %llu %llu %llu %llu %llu %llu; finished %llu, deferred %llu\n",
+                         c[28], c[30] / (double)c[28], c[29], c[31], c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
+      if (c[28] && !m->far_lanes) fprintf(stderr, "[smatrix]   ... their cycles: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f\n",
+                                          c[40] / (double)c[28], c[41] / (double)c[28], c[42] / (double)c[28], c[43] / (double)c[28]);
       fprintf(stderr, "[smatrix] k_grow_rest_lds: steps %llu rounds %llu | most steps of a wave %llu, most rounds %llu | trips %llu, most of a wave %llu | per round: losers %.2f blocked %.2f committed %.2f\n",
               c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
       (void)hipFree(m->rest_dbg);
@@ -2204,7 +2227,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
       delete static_cast<HostPipe*>(m->host_pipe);
-      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release();
+      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
