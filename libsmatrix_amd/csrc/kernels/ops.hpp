@@ -1068,10 +1068,13 @@ constexpr uint32_t AGG_SLOTS = 2 * AGG_TILE;       // LDS hash slots (load <= 1/
 #ifndef SMX_AGG_SGPRS
 #define SMX_AGG_SGPRS 80
 #endif
+#ifndef SMX_AGG_CLU_VGPRS
+#define SMX_AGG_CLU_VGPRS 64
+#endif
 // CLU: the instantiation for clustered tables with a hint table (ArenaHead) -- the slow path asks for the hint after HINT_BUDGET
 // cells instead of walking PROBE_BUDGET dependent loads first (a tile waits for its slowest lane)
-template <int OP, uint32_t ST = 1, bool RET = true, bool CLU = false>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare); RET: results wanted
-__global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_apply_agg(
+template <int OP, uint32_t ST, bool RET, bool CLU>     // ST: op stride in words, compile-time here (the kernel has no SGPR to spare); RET: results wanted
+__device__ __forceinline__ void apply_agg_body(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
@@ -1304,6 +1307,25 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
     for (uint32_t k = 0; k < AGG_OPT; k++)
       if (dmask_k & (1u << k)) defer[at++] = j[k];
   }
+}
+
+template <int OP, uint32_t ST = 1, bool RET = true, bool CLU = false>
+__global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) void k_apply_agg(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
+  static_assert(!CLU, "clustered tables: k_apply_agg_clu");
+  apply_agg_body<OP, ST, RET, false>(ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer);
+}
+// The clustered instantiation as a kernel of its own, held to 64 VGPRs (it compiled to 68, two spills now): a CU then holds TWO
+// 1024-lane workgroups like the scrambled-id kernel does, 2.04 -> 1.66 ms per launch on the dense-id stream.  (A kernel of its
+// own because the attribute changes the code of every instantiation it is put on, and the headline's is frozen.)
+template <int OP>
+__global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG_SGPRS))) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_apply_agg_clu(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer) {
+  apply_agg_body<OP, 1, true, true>(ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer);
 }
 
 // ---- set batches: the same fold, keeping each key's LAST op --------------------------------------------------

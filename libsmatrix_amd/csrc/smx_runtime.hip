@@ -916,7 +916,7 @@ void launch_apply_agg(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx,
   } else if (m->in_stride == 3) {
     hipLaunchKernelGGL((k_apply_agg<OP, 3>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   } else if (m->d_hints && m->clustered) {
-    hipLaunchKernelGGL((k_apply_agg<OP, 1, true, true>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
+    hipLaunchKernelGGL((k_apply_agg_clu<OP>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   } else {
     hipLaunchKernelGGL((k_apply_agg<OP>), grid, block, 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer);
   }

@@ -4,7 +4,7 @@ import csv, glob, sys
 d = sys.argv[1]; last = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
-idx = [i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'] and t['Grid_Size_X'] == '8388608']
+idx = [i for i, t in enumerate(tr) if ('k_apply_agg<2' in t['Kernel_Name'] or 'k_apply_agg_clu<2' in t['Kernel_Name']) and t['Grid_Size_X'] == '8388608']
 i0 = idx[-last]; agg = {}; cnt = {}
 i1 = len(tr)
 if len(sys.argv) > 3:

@@ -2,7 +2,7 @@
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
-idx = [i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'] and t['Grid_Size_X'] == '8388608']
+idx = [i for i, t in enumerate(tr) if ('k_apply_agg<2' in t['Kernel_Name'] or 'k_apply_agg_clu<2' in t['Kernel_Name']) and t['Grid_Size_X'] == '8388608']
 for i0 in idx[-4:]:
     out = []
     for t in tr[i0:i0 + 60]:

@@ -4,7 +4,7 @@ import csv, glob, sys
 d = sys.argv[1]; which = sys.argv[2] if len(sys.argv) > 2 else "-1"
 f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
 tr = sorted(csv.DictReader(open(f)), key=lambda t: int(t['Start_Timestamp']))
-idx = [i for i, t in enumerate(tr) if 'k_apply_agg<2' in t['Kernel_Name'] and t['Grid_Size_X'] == '8388608']
+idx = [i for i, t in enumerate(tr) if ('k_apply_agg<2' in t['Kernel_Name'] or 'k_apply_agg_clu<2' in t['Kernel_Name']) and t['Grid_Size_X'] == '8388608']
 if which == "last-growing":
     # the last step of the growing table: the last full-grid launch of the folding kernel that is followed by a growth round
     # (the all-hit replays behind it have none; since round 4 the first batch of an empty matrix has no such launch at all)
