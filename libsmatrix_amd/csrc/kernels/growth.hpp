@@ -938,9 +938,10 @@ __global__ void k_round_advance(Ctl* ctl, const uint32_t* rebal, DirSlot* dir, u
   ctl->spec_nrebal0 = ctl->n_rebal;
   ctl->spec_dirfull0 = ctl->dir_full;
   for (int k = 0; k < 4; k++) ctl->spec_nkind0[k] = ctl->n_kind[k];
-  const uint32_t keep_long = ctl->n_long, keep_oom = ctl->arena_oom, keep_long_ops = ctl->n_long_ops;
+  const uint32_t keep_long = ctl->n_long, keep_oom = ctl->arena_oom, keep_long_ops = ctl->n_long_ops, n_absent = ctl->n_absent;
   uint64_t* z = reinterpret_cast<uint64_t*>(ctl);
   for (uint32_t i = 0; i < CTL_ROUND_BYTES / 8; i++) z[i] = 0;
+  ctl->n_defer = n_absent;                           // (the list the next round WRITES begins with the ops the folding kernel put there)
   ctl->n_long = keep_long;                           // (sticky for the batch: the host switches the retries to lane-per-op)
   ctl->n_long_ops = keep_long_ops;                   // (summed over the rounds of a chain)
   ctl->arena_oom = keep_oom;

@@ -98,7 +98,8 @@ struct Ctl {
   uint32_t n_long;       // the folding kernel deferred ops whose probe outran its budget (the lane-per-op kernel takes them)
   uint32_t n_long_ops;   // ... how many ops the lane-per-op WRITE kernel finished through the wave-cooperative probe in this round: a few on
                          // any large table at load 1/2, percents of a batch on a clustered one (dense ids) -- Matrix::clustered
-  uint32_t pad0;
+  uint32_t n_absent;     // (clustered folding kernel, ArenaHead::absent_list) ops deferred into the second list: they wait for prep, the pass in
+                         // front of it does not see them; k_round_advance starts that pass's output list behind them
   // ---- persistent ----
   uint32_t dir_used;     // rows in the directory
   uint32_t pad1;

@@ -102,6 +102,11 @@ struct ArenaHead {
   // cells have been handed out -- parallel to far_occ
   const unsigned long long* far_occ0;
   uint32_t* far_clm;
+  // (round 5) the clustered folding kernel keeps the ops it defers in TWO lists while this is set: ops whose probe outran the
+  // budget in the usual one -- the pass in front of prep finishes most of them --, ops whose key is known to be ABSENT from a row
+  // that stands at its threshold (or from no row at all) here: they wait for prep whatever that pass does, which therefore
+  // never sees them (Ctl::n_absent, k_round_advance)
+  uint32_t* absent_list;
 };
 static_assert(sizeof(ArenaHead) <= 128, "unit 0 of the arena");
 #ifndef SMX_HINT_BUDGET
@@ -1245,16 +1250,17 @@ __device__ __forceinline__ void apply_agg_body(
 #pragma unroll
     for (uint32_t q = 0; q < AGG_OPT; q++) {
       if (!(have & (1u << q))) continue;
-      bool deferred = false;
+      bool deferred = false, waits = false;                  // waits: deferred for a structure change, not for a long probe
       if (dbg == 4 && !(fast & (1u << q))) { old[q] = 0; fast |= 1u << q; }     // 4: the slow path (inserts, collisions) left out
       if (full & (1u << q)) {
-        deferred = true;                                     // the row stands at its threshold: prep doubles it
+        deferred = waits = true;                             // the row stands at its threshold: prep doubles it
       } else if (!(fast & (1u << q))) {
         // a probe that outruns the budget (clustered dense ids) is not walked here, one lane at a time: the op is
         // deferred and the lane-per-op kernel finishes it with the wave-cooperative window probe
         LongProbe lp{false, nullptr, 0, 0};
         uint32_t res = apply_one<OP, SMX_AGG_PATIENT, 1>(dir, dmask, arena, (uint32_t)kk[q], (uint32_t)(kk[q] >> 32), tot[q], &deferred, &lp, dbg == 5, !RET,
                                                          false, nullptr, CLU ? HINT_BUDGET : PROBE_BUDGET, CLU);
+        waits = deferred;                                    // (no row, no ticket, no empty cell: apply_row)
         if (lp.need) {
           // (round 4) ... unless the key's cell is remembered (ArenaHead): then this is a hit like any other.  One hinted key in
           // 256 counts for 256 long probes: the host's evidence that the table is still clustered
@@ -1268,12 +1274,15 @@ __device__ __forceinline__ void apply_agg_body(
         old[q] = OP == OP_INCR ? res - tot[q] : res + tot[q];
       }
       l_sum[hh[q]] = old[q];                                  // the cell's value before the tile
-      reinterpret_cast<uint32_t*>(&l_key[hh[q]])[0] = deferred ? 1u : 0u;
+      reinterpret_cast<uint32_t*>(&l_key[hh[q]])[0] = deferred ? (CLU && waits ? 2u : 1u) : 0u;
     }
   }
   __syncthreads();
   // phase 3
   uint32_t dmask_k = 0;          // which of this lane's ops are deferred
+  uint32_t amask_k = 0;          // (CLU) ... into the list of the ops that wait for prep (ArenaHead::absent_list)
+  uint32_t* alist = nullptr;
+  if constexpr (CLU) alist = reinterpret_cast<const ArenaHead*>(arena)->absent_list;
 #pragma unroll
   for (uint32_t k = 0; k < AGG_OPT; k++) {
     bool deferred = false;
@@ -1283,11 +1292,13 @@ __device__ __forceinline__ void apply_agg_body(
       if (lp.need) { deferred = true; ctl->n_long = 1; }
       if (!deferred && RET) out[j[k]] = r;
     } else if (slot[k] != ~0u) {
-      deferred = reinterpret_cast<uint32_t*>(&l_key[slot[k]])[0] != 0;
+      const uint32_t status = reinterpret_cast<uint32_t*>(&l_key[slot[k]])[0];
+      deferred = status != 0;
       if (!deferred && RET) {                                  // (!RET: the caller does not want the results)
         const uint32_t old = l_sum[slot[k]];
         out[j[k]] = OP == OP_INCR ? old + pre[k] + V[k] : old - pre[k] - V[k];
       }
+      if (CLU && status == 2u && alist) { amask_k |= 1u << k; deferred = false; }
     }
     if (deferred) dmask_k |= 1u << k;
   }
@@ -1295,17 +1306,30 @@ __device__ __forceinline__ void apply_agg_body(
   // counter was the kernel's critical path when a few % of the ops defer)
   __syncthreads();                       // everybody is done with l_sum / l_n
   if (tid == 0) l_n = 0;
+  uint32_t* l_abs = &l_sum[1];           // (CLU) [0] the tile's ops for the second list, [1] their place in it
+  if (CLU && tid == 0) l_abs[0] = 0;
   __syncthreads();
   uint32_t mine = __popc(dmask_k), at = 0;
   if (mine) at = atomicAdd(&l_n, mine);
+  uint32_t amine = 0, aat = 0;
+  if constexpr (CLU) { amine = __popc(amask_k); if (amine) aat = atomicAdd(&l_abs[0], amine); }
   __syncthreads();
   if (tid == 0 && l_n) l_sum[0] = atomicAdd(&ctl->n_defer, l_n);
+  if (CLU && tid == 64 && l_abs[0]) l_abs[1] = atomicAdd(&ctl->n_absent, l_abs[0]);
   __syncthreads();
   if (mine) {
     at += l_sum[0];
 #pragma unroll
     for (uint32_t k = 0; k < AGG_OPT; k++)
       if (dmask_k & (1u << k)) defer[at++] = j[k];
+  }
+  if constexpr (CLU) {
+    if (amine) {
+      aat += l_abs[1];
+#pragma unroll
+      for (uint32_t k = 0; k < AGG_OPT; k++)
+        if (amask_k & (1u << k)) alist[aat++] = j[k];
+    }
   }
 }
 

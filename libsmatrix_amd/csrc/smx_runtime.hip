@@ -664,6 +664,8 @@ struct Matrix {
   uint4* d_hints = nullptr;
   uint32_t hint_lg = 22;
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
+  uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
+  bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
   void* host_pipe = nullptr;            // HostPipe: the staging of large host-pointer batches (smatrix_apply_batch and friends)
@@ -795,6 +797,14 @@ void ensure_hints(Matrix* m, hipStream_t s) {
 // a 32-bit word of ArenaHead (unit 0 of the arena)
 void arena_head_set(Matrix* m, size_t offset, uint32_t value, hipStream_t s) {
   HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->arena.base + offset), (int)value, 1, s));
+}
+// ArenaHead::absent_list: where the clustered folding kernel puts the ops that wait for prep (nullptr: one deferred list)
+void absent_list_set(Matrix* m, uint32_t* list, hipStream_t s) {
+  if (m->absent_list_dev == list) return;
+  m->absent_list_dev = list;
+  const uint64_t v = reinterpret_cast<uint64_t>(list);
+  arena_head_set(m, offsetof(ArenaHead, absent_list), (uint32_t)v, s);
+  arena_head_set(m, offsetof(ArenaHead, absent_list) + 4, (uint32_t)(v >> 32), s);
 }
 
 // The device-side helpers of a clustered matrix brought in line with m->clustered: the hint table, and the rows' at-home
@@ -1411,8 +1421,17 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       HIP_OK(hipGetLastError());
       HIP_OK(hipMemcpyAsync(&m->d_ctl->n_defer, &n, 4, hipMemcpyHostToDevice, s));
       timed0 = false;
-    } else
-    launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
+    } else {
+      // (round 5) when the pass in front of prep follows this op round (the condition of `pre_pass` below), the clustered folding
+      // kernel sets the ops that wait for prep aside in that pass's OUTPUT list -- keys known to be absent from rows at their
+      // threshold: 30 % of the deferred ops of a late dense-id batch, 80-90 % of a young table's, each of which cost the pass a
+      // wave's trip for nothing (ArenaHead::absent_list, Ctl::n_absent)
+      if (op == OP_INCR || op == OP_DECR) {
+        const bool pass_follows = (chained || (round == 0 && idx == nullptr && m->home_on && m->far_join && n >= (1u << 16))) && m->clustered;
+        absent_list_set(m, pass_follows && m->absent_split && m->dbg_after == 0 ? m->defer[1].p : nullptr, s);
+      }
+      launch_apply_op(m, op, s, cur_n, idx, x, y, v, out, dl);
+    }
     DBG_STEP(m, s, m->long_probes ? "op kernel (lane per op)" : "op kernel");
 #if defined(SMX_AGG_DBG) && SMX_AGG_DBG == 5
     // measurement build "inserts without tickets": rows overfill and their deferred ops never converge -- only the
@@ -1429,7 +1448,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       // walking it through a round per doubling
       if (!all_new) ctl_read(m, s);                          // (an empty matrix defers the whole batch: nothing to read)
       if (timed0) { account_kernel_time(m, op, n); timed0 = false; }
-      const uint32_t nd0 = all_new ? n : m->h_ctl->n_defer;
+      const uint32_t nd0 = all_new ? n : m->h_ctl->n_defer + m->h_ctl->n_absent;
       m->expect_bulk = (uint64_t)nd0 * 8 >= n;
       // worth it when a LARGE share of the batch is pending (bulk loads, the first batch of a matrix: every op names a
       // row that does not exist yet).  At 10-15 % -- batches 1 and 2 of config 2 -- grouping costs more than the rounds
@@ -1439,6 +1458,12 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         rounds_this_batch++;
         m->st.deferred_ops += nd0;
         m->tasks.need(std::min<uint64_t>(cur_n, m->dir_size));
+        if (!all_new && m->h_ctl->n_absent) {
+          // (the folding kernel kept two lists for a pass that does not follow now: one list again)
+          HIP_OK(hipMemcpyAsync(dl + m->h_ctl->n_defer, m->defer[1].p, (size_t)m->h_ctl->n_absent * 4, hipMemcpyDeviceToDevice, s));
+          HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->d_ctl->n_defer), (int)nd0, 1, s));
+          HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->d_ctl->n_absent), 0, 1, s));
+        }
         uint32_t* dl2 = m->defer[1].p;
         const uint32_t nd2 = op == OP_INCR   ? run_bulk_t<OP_INCR>(m, nd0, dl, dl2, x, y, v, out, s)
                              : op == OP_DECR ? run_bulk_t<OP_DECR>(m, nd0, dl, dl2, x, y, v, out, s)
@@ -2135,6 +2160,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
+  if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
     dev_malloc(&m->rest_dbg, 512);
