@@ -171,7 +171,12 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
  * reference's IO thread writes under per-row read locks only (:929-960): callers on other threads keep their latency
  * (measured: a 1 GB flush, batch gets p99 23 -> 25 us).  A row that changes while a flush writes goes out with the next.
  * SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch (inside that call), SMATRIX_FSYNC=1 adds fsync() after the
- * row blocks and after the entries.  Memory mode: no-op.  Returns 0. */
+ * row blocks and after the entries.  Memory mode: no-op.  Returns 0.
+ * Lock order: matrix lock, then the file lock, and a flush keeps the file lock while it writes.  smatrix_flush waits for a
+ * flush in flight WITHOUT the matrix lock; a SMATRIX_FLUSH_EVERY checkpoint and smatrix_close wait for it while they hold the
+ * matrix lock (they are inside a call that owns it), so callers on other threads wait for the rest of that write -- at most one
+ * snapshot, 2 GB, a few tenths of a second.  Where that matters run checkpoints OR the background flusher
+ * (SMATRIX_FLUSH_MS=0 turns it off), not both. */
 int smatrix_flush(smatrix_t* self);
 /* EXPERIMENTAL, no reference counterpart (the reference's files only grow: resized rows leave their old block behind,
  * src/smatrix.c:430-436, and so do this library's -- same format, same leak): rewrites the backing file without those

@@ -731,9 +731,11 @@ void ensure_free_cap(Matrix* m, uint32_t c, uint64_t extra, hipStream_t s) {
   const uint64_t have = m->free_cnt[c] > 0 ? (uint64_t)m->free_cnt[c] : 0;
   const uint64_t need = have + extra;
   if (need <= m->fl.cap[c]) return;
-  // (twice what is asked for: a young table's task counts creep up from batch to batch -- 116 818, 118 736, ... -- and a stack
+  // (more than what is asked for: a young table's task counts creep up from batch to batch -- 116 818, 118 736, ... -- and a stack
   //  sized exactly was reallocated in every one of them, each time with a hipFree that waits for the device: 0.4 ms a batch)
-  const uint64_t ncap = std::max<uint64_t>(2 * need, (uint64_t)m->fl.cap[c] * 2);
+  // (a quarter on top, not twice -- every size class gets room for ALL tasks of a round, 7 stacks of 2 x 4 bytes per
+  //  task were 0.9 GB at 2^24 rows; the creep is a few % per batch)
+  const uint64_t ncap = std::max<uint64_t>(need + std::max<uint64_t>(need / 4, 65536), (uint64_t)m->fl.cap[c] * 5 / 4);
   uint32_t* np = nullptr;
   dev_malloc(&np, ncap * sizeof(uint32_t));
   if (have) HIP_OK(hipMemcpyAsync(np, m->fl.list[c], have * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));

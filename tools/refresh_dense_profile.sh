@@ -15,7 +15,7 @@ rm -rf $O/kt_dense
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmcd_$tag -- python3 $R/tools/probe/dense_steps.py 24 > /dev/null 2>&1
-  for k in k_apply_wpo_far k_far_scan k_grow_rest_lds "k_apply_agg<2, 1u, true, true>" "k_apply<0, true>" k_far_rows k_far_keys; do
+  for k in k_apply_wpo_far k_far_scan k_grow_rest_lds "k_apply_agg_clu<2>" "k_apply<0, true>" k_far_rows k_far_keys; do
     python3 $R/tools/probe/pmc_kernel.py $O/pmcd_$tag "$k"
   done > $O/prof_dense_pmc_$tag.txt
   rm -rf $O/pmcd_$tag
