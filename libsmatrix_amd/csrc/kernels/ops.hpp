@@ -613,7 +613,9 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
 // HM: 0 the matrix has no hint table (ArenaHead; the instantiation every scrambled-id stream runs: nothing of it is compiled in),
 //     1 it has one, 2 look (the wave-per-op kernel: clustered tables only)
 // FAR: the pass in front of prep of a clustered write batch, with the batch's far join at hand (ArenaHead::far_on)
-template <int OP, bool WPO = false, int HM = 0, bool FAR = false>
+// SHORT: a lane per op that does NOT finish long probes: an op whose probe outruns the lane's budget (and the hint table) is
+//        deferred -- the first half of a clustered table's retry, see k_apply_short
+template <int OP, bool WPO = false, int HM = 0, bool FAR = false, bool SHORT = false>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -666,6 +668,9 @@ __device__ __forceinline__ void apply_body(
         lp.need = false;
         r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
       }
+    }
+    if constexpr (SHORT) {
+      if (lp.need) { lp.need = false; deferred = true; was_long = true; }
     }
     uint32_t p_coop = PROBE_NONE;                           // where the wave-cooperative probe ended
     // the far join of this batch (the wave-per-op pass in front of prep): the key's cell is known, or the key is known to have
@@ -1019,6 +1024,25 @@ void k_apply_wpo_far(
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
   apply_body<OP, true, 2, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+}
+
+// (round 5) The retry of a clustered table in two halves.  After the growth round most ops of the list are short again -- a key
+// that was absent from a full row goes into a table that has just doubled -- but a wave per op is priced for the long ones (2.8 ns
+// per op: 4 ms for the 1.4 M-op lists of a young dense-id table), and a lane per op finishing its long probes inside the wave makes
+// the 63 others wait for each.  So: k_apply_short takes everything a lane's budget and the hint table settle and DEFERS the rest;
+// k_apply_wpo then runs over what is left.
+template <int OP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS))) void k_apply_short(
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
+    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
+    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
+  apply_body<OP, false, 2, false, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+}
+// between the two: the list the first half wrote becomes the list the second half reads (nothing else of the round's state moves)
+__global__ void k_list_advance(Ctl* ctl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ctl->n_prev = ctl->n_defer;
+  ctl->n_defer = 0;
 }
 
 template <int OP>

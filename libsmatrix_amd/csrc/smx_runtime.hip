@@ -665,6 +665,7 @@ struct Matrix {
   uint32_t hint_lg = 22;
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
+  bool retry_split = true;              // SMATRIX_RETRY_SPLIT=0: the retry of a clustered table a wave per op in one launch
   bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
@@ -1540,6 +1541,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     if (far_joined) arena_head_set(m, offsetof(ArenaHead, far_on), 0u, s);     // (rows are about to double: the join's view of the tables ends here)
     DBG_STEP(m, s, "k_prep");
     uint32_t nd_chain0 = 0;
+    bool retry_halves = false;
     if (chained) {
       // ---- the rest of the chain: growth for the rows round 0's prep flagged, the retry, its prep -- no read-back between
       const uint32_t est_nk[4] = {std::max<uint32_t>(2 * m->spec_nk_prev[0], 4096), std::max<uint32_t>(2 * m->spec_nk_prev[1], 1024),
@@ -1552,7 +1554,25 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       const uint32_t est_nd = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n);
       uint32_t* dl1 = pre_pass ? m->defer[0].p : m->defer[1].p;       // (the list the retry reads sits in the other one)
       const dim3 rgrid(std::min<uint32_t>(blocks_for(est_nd), 16384));
-      if (m->clustered && est_nd <= m->wpo_max) {
+      if (m->clustered && est_nd <= m->wpo_max && m->retry_split && m->d_hints) {
+        // the retry in two halves (k_apply_short): a lane per op for what is short again, then a wave per op over the rest; the
+        // list that is left ends up in the buffer the retry READ, so the round's parity moves on by one (below)
+        uint32_t* dl0 = dl;
+        const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * 64), 65536));
+        switch (op) {
+          case OP_SET:  hipLaunchKernelGGL((k_apply_short<OP_SET>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+          case OP_INCR: hipLaunchKernelGGL((k_apply_short<OP_INCR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+          default:      hipLaunchKernelGGL((k_apply_short<OP_DECR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
+        }
+        hipLaunchKernelGGL(k_list_advance, dim3(1), dim3(64), 0, s, m->d_ctl);
+        switch (op) {
+          case OP_SET:  hipLaunchKernelGGL((k_apply_wpo<OP_SET>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl1, x, y, v, out, dl0, m->in_stride); break;
+          case OP_INCR: hipLaunchKernelGGL((k_apply_wpo<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl1, x, y, v, out, dl0, m->in_stride); break;
+          default:      hipLaunchKernelGGL((k_apply_wpo<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl1, x, y, v, out, dl0, m->in_stride); break;
+        }
+        dl1 = dl0;
+        retry_halves = true;
+      } else if (m->clustered && est_nd <= m->wpo_max) {
         const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * 64), 65536));      // (a wave per op: launch_apply)
         switch (op) {
           case OP_SET:  hipLaunchKernelGGL((k_apply_wpo<OP_SET>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
@@ -1617,7 +1637,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       }
       if (nd_chain0 == 0) { structure_stable = true; break; }  // round 0 deferred nothing: the rest of the chain ran empty
       cur_n = nd_chain0;
-      round = pre_pass ? 2 : 1;                                // (the next round writes the list that `dl` is NOT)
+      round = (pre_pass ? 2 : 1) + (retry_halves ? 1 : 0);     // (the next round writes the list that `dl` is NOT)
     } else if (pre_pass) {
       // the host-driven round 0 with the pass in front of prep: the list that is left sits in defer[1], so the next round is numbered 2
       if (far_joined) { m->far_rows_seen = m->h_ctl->n_big; m->far_units_seen = m->h_ctl->n_units; m->far_nd_seen = m->h_ctl->far_nd; }
@@ -2163,6 +2183,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
   if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
+  if (const char* a = getenv("SMATRIX_RETRY_SPLIT")) m->retry_split = *a != '0';
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
     dev_malloc(&m->rest_dbg, 512);
