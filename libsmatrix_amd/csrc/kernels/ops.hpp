@@ -270,9 +270,9 @@ __device__ inline uint32_t far_walk(const uint64_t* cells, uint32_t mask, const 
 // CLAIMED inserts of the far join.  The new far keys of a clustered row all walk to the same free cells -- the holes of their run,
 // then the cells behind it -- and each insert must see the one before it: 2 000 new keys of one row were 2 000 dependent
 // compare-and-swaps on the cell at the front, the pass's critical path.  With the join such a key is known to be absent and the
-// free cells of its row are the clear bits of the occupancy words, so an insert CLAIMS its cell there first: the first clear bit
-// at/after the key's own first free cell that it manages to set (one atomic OR per attempt; the word the OR returns is fresh, so
-// a crowded front costs one atomic per 64 cells, not one per cell) names a cell nobody else will claim; the key is then stored
+// free cells of its row are the clear bits of the occupancy words, so an insert CLAIMS its cell there first: walking the words
+// from the key's own first free cell on, it takes a RANK in the first word that has free cells left (one fetch-add; the r-th
+// claimer owns the r-th cell that was free at the scan -- see the body), sets that cell's bit in the live word and stores the key
 // with a compare-and-swap (a cell that a plain insert took in the meantime just sends the claimer on).  The table ends as SOME
 // order of the reference's inserts would leave it (src/smatrix.c:343-380): every cell between a key's home and its own was
 // taken at the scan or has its bit set -- claimed by an op that holds a ticket and stores its key there, or found taken.
