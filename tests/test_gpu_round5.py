@@ -220,6 +220,18 @@ def test_dense_zipf_stream_with_and_without_the_far_join(G, oracle_mod, monkeypa
     assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
     for r in rows.tolist():
         assert g.row_info(r) == o.row_info(r), r
+        # the cells are the oracle's (as a set: a batch is some serialisation of its ops), and every key sits where a probe from
+        # its home finds it -- no empty cell in between: the claimed inserts (by rank in the occupancy words) leave no hole
+        a = np.asarray(g.row_slots(r)); b = np.asarray(o.row_slots(r))
+        ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
+        ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
+        assert ka.shape == kb.shape and (ka == kb).all(), (r, "cells")
+        ne = (a[:, 0] != 0) | (a[:, 1] != 0)
+        size = a.shape[0]
+        pos = np.flatnonzero(ne); empties = np.flatnonzero(~ne)
+        home = a[pos, 0].astype(np.int64) & (size - 1)
+        nxt = empties[np.searchsorted(empties, home) % empties.size]
+        assert (((nxt - home) % size) > ((pos - home) % size)).all(), (r, "an empty cell inside a probe sequence")
     assert (g.apply(0, x, y) == o.apply(0, x, y)).all()
     g.close(); o.close(); gen.close()
 
