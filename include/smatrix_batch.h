@@ -17,7 +17,8 @@
  * Two flavours: host pointers (staged through HBM by the library; calls above two chunks of 2^21 ops -- SMATRIX_HOST_CHUNK_LG --
  * run as a three-stage pipeline: the caller's arrays are copied into pinned memory by a pool of threads and uploaded while the
  * kernels of the previous chunk run and the results of the one before travel back; a write batch's chunks are applied in order,
- * so the call behaves like ONE batch -- set: the later op still wins.  2^24-op calls: 3.0 G incr/s, 4.0-4.7 G get/s, PCIe
+ * so the call behaves like ONE batch -- set: the later op still wins; a chunk whose amounts v[] are all one value is filled on
+ * the device instead of uploaded.  2^24-op calls: 3.1-3.5 G incr/s, 4.4-5.0 G get/s, PCIe
  * included; this is the shape a JNI / Ruby batch binding has, cf. src/smatrix_jni.c:95-111) and `_dev`
  * (pointers are device memory on the matrix's GPU; work is enqueued on
  * `hip_stream` -- a hipStream_t passed as void*; NULL = the legacy default stream, i.e. what

@@ -258,6 +258,14 @@ def test_large_host_batches_run_in_chunks_like_one_call(G, oracle_mod, monkeypat
             a, b = g.m.apply_batch(op, x, y, v), o.apply(op, x, y, v)
             assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), (lg, op)
         g.m.apply_batch(2, x, y, v, results=False); o.apply(2, x, y, v)           # no result array
+        # one amount for the whole call (incr by 3): such chunks are filled on the device instead of uploaded -- and a call whose
+        # amounts are equal but for ONE op somewhere (not where the feeder samples) must take the upload
+        c3 = np.full(n, 3, np.uint32)
+        a, b = g.m.apply_batch(2, x, y, c3), o.apply(2, x, y, c3)
+        assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), (lg, "one amount")
+        c3[n // 2 + 4097] = 7
+        a, b = g.m.apply_batch(2, x, y, c3), o.apply(2, x, y, c3)
+        assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), (lg, "one amount but for one op")
         sv = np.random.default_rng(7).integers(1, 1 << 30, n, dtype=np.uint32)    # set: duplicates far apart, the later op wins
         a = g.m.set_batch(x, y, sv); o.apply(1, x, y, sv)
         assert (a == sv).all()
