@@ -656,19 +656,29 @@ __device__ __forceinline__ void apply_body(
       V = OP != OP_GET ? vs[at] : 0u;
       d = dir_find(dir, dmask, xs[at], &s);
       if (!d || s.z == 0) deferred = (OP != OP_GET);      // get on an absent row: 0, creates nothing (S1)
+      else if (WPO && FAR && OP != OP_GET && Y != 0) {
+        // (the pass with the join: the lane does not even look at the home cell -- the join's table is asked first, and what it
+        //  does not know goes to the hint table and the wave's probe FROM the home cell: one dependent load less per op, two for
+        //  the keys the join knows.  What apply_row does first for every writer is done here: the row is marked dirty.)
+        if (!(s.x & META_DIRTY)) d->meta = s.x | META_DIRTY;
+        const uint32_t mask = (1u << meta_lg(s.x)) - 1u;
+        lp = LongProbe{true, row_cells(arena, s.z), mask, Y & mask};
+      }
       else r = apply_row<OP, true, 1>(d, s, arena, Y, V, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp, false, false, false, nullptr, budget, use_home);
     }
     // a probe that has used up its budget: is the key's cell remembered?  (ArenaHead: dense ids)
     // was_long: the evidence for "this table is clustered" -- a probe of more than PROBE_BUDGET cells, whatever the budget was
     bool was_long = lp.need && !has_hints;
-    if (has_hints && lp.need) {
+    bool far_none = true;                                   // (WPO && FAR) the join's table does not know this op's key
+    const auto ask_hints = [&] {
       const uint32_t p = hint_find(arena, lp.cells, lp.mask, Y);
       if (p != 0xFFFFFFFFu) {
         was_long = ((p - Y) & lp.mask) > PROBE_BUDGET;
         lp.need = false;
         r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
       }
-    }
+    };
+    if (!(WPO && FAR) && has_hints && lp.need) ask_hints();
     if constexpr (SHORT) {
       if (lp.need) { lp.need = false; deferred = true; was_long = true; }
     }
@@ -686,6 +696,7 @@ __device__ __forceinline__ void apply_body(
         const FarHit fh = far_find(arena, lp.cells, Y);
         if (hdbg) h_find = clock64() - hf0;
         if (ah->dbg && !hdbg && (t & 63u) == 0) atomicAdd(&ah->dbg[16 + fh.state], 64ull);
+        far_none = fh.state != FAR_FOUND && fh.state != FAR_ABSENT;
         if (fh.state == FAR_FOUND) {
           if (has_hints) was_long = ((fh.slot - Y) & lp.mask) > PROBE_BUDGET;
           lp.need = false;
@@ -696,7 +707,10 @@ __device__ __forceinline__ void apply_body(
           if ((OP == OP_INCR || OP == OP_DECR) && !ah->far_overflow) {
             // one op per new key inserts it; another one naming the same key waits for the retry (it finds the key in place)
             if (atomicCAS(&fh.entry->w, 0u, 1u) == 0u) ranked = true;
-            else { lp.need = false; deferred = true; was_long = true; }
+            else {
+              if (WPO && has_hints) ask_hints();              // (the op that holds the claim may have put the key in already)
+              if (lp.need) { lp.need = false; deferred = true; was_long = true; }
+            }
           }
           if (!WPO && lp.need) {
             // a lane per op: the lane walks by the occupancy words itself (far_walk), all lanes of the wave side by side
@@ -725,6 +739,7 @@ __device__ __forceinline__ void apply_body(
         }
       }
     }
+    if (WPO && FAR && has_hints && lp.need && far_none) ask_hints();
     if (tdbg) tc2 = clock64();
     long long t_coop = 0;
     while (__any(lp.need)) {                              // wave-uniform: long probes are finished by the whole wave
