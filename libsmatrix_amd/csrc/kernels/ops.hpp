@@ -945,6 +945,12 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     // the general path (big rows: sub-counter quotas; long probe sequences: the wave-cooperative probe)
     uint32_t r = 0;
     if (general) r = apply_row<OP_INCR, true, 1>(d, s, arena, Y, 0u, Y & ((1u << meta_lg(s.x)) - 1u), &deferred, &lp, false, false, false, nullptr, PROBE_BUDGET, use_home);
+    {
+      // (the host's evidence for "this table is clustered", as in the op kernels: the cold start of a dense-id stream must find
+      //  out in its first rounds -- its last four doublings of the hot rows took 8, 16, 30 and 49 ms by priority probing)
+      const uint64_t lm = __ballot(lp.need);
+      if (lm && __lane_id() == 0) atomicAdd(&ctl->n_long_ops, (uint32_t)__popcll(lm));
+    }
     while (__any(lp.need)) {
       const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home);
       if (lp.need) {
