@@ -846,14 +846,20 @@ constexpr uint32_t INS_THREADS = 1024;
 // Round 4: the keys travel PACKED -- n 64-bit keys (x << 32 | y) in `kin`, the ones that stay deferred written to `kout` the same
 // way (one reservation per workgroup, as before).  A round used to read an index list and gather x and y of every listed op from
 // the batch's arrays (two random 4-byte loads per key and round out of 134 MB, again in k_prep); now every round streams its input.
+// wpo (round 5, clustered tables): a WAVE per key -- lane 0 holds it, the wave finishes its long probe, as in k_apply_wpo.  The late
+// rounds of a dense-id cold start are a few 10^5 keys of the hottest rows, every one a walk to the end of a long run: a lane per key,
+// a wave took its 64 walks one after the other (8, 16, 30, 49 ms for the last four rounds of the stream's first batch).
 __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const unsigned long long* __restrict__ kin,
-    unsigned long long* __restrict__ kout) {
+    unsigned long long* __restrict__ kout, uint32_t wpo) {
   __shared__ uint32_t l_row[2 * INS_THREADS], l_cnt[2 * INS_THREADS], l_grant[2 * INS_THREADS];
   __shared__ uint32_t l_n, l_base;
-  for (uint64_t t064 = (uint64_t)blockIdx.x * INS_THREADS; t064 < n; t064 += (uint64_t)gridDim.x * INS_THREADS) {   // block-uniform
-    const uint32_t t = (uint32_t)t064 + threadIdx.x;
-    const bool live = t < n;
+  const uint64_t n_lanes = wpo ? (uint64_t)n * 64u : (uint64_t)n;
+  const uint32_t lane_budget = wpo ? 4u : PROBE_BUDGET;
+  for (uint64_t t064 = (uint64_t)blockIdx.x * INS_THREADS; t064 < n_lanes; t064 += (uint64_t)gridDim.x * INS_THREADS) {   // block-uniform
+    const uint64_t tl = t064 + threadIdx.x;
+    const uint32_t t = wpo ? (uint32_t)(tl >> 6) : (uint32_t)tl;
+    const bool live = tl < n_lanes && (!wpo || (tl & 63u) == 0);
     for (uint32_t i = threadIdx.x; i < 2 * INS_THREADS; i += INS_THREADS) { l_row[i] = 0xFFFFFFFFu; l_cnt[i] = 0; }
     if (threadIdx.x == 0) l_n = 0;
     unsigned long long key = 0;
@@ -885,7 +891,7 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
           const uint64_t c = cells[pos];
           if (cell_key(c) == Y) break;                           // it exists: nothing to do
           if (c == 0) { need = true; break; }
-          if (steps > PROBE_BUDGET) { general = true; break; }
+          if (steps > lane_budget) { general = true; break; }
           pos = (pos + 1) & mask;
         }
         if (need && meta_lg(s.x) < BIG_LG && s.w > (mask + 1u) / 2u) { need = false; deferred = true; }     // (the snapshot already shows the row full)

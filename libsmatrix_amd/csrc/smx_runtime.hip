@@ -1314,8 +1314,10 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     unsigned long long* kout = (round & 1) ? m->cold_keys[0].p : (m->cold_keys[1].need_on(cur_n, s), m->cold_keys[1].p);
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
     ctl_reset_round(m, s);
-    hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base,
-                       cur_n, kin, kout);
+    // (clustered tables, lists up to 2^21 keys: a wave per key -- k_insert_keys)
+    const uint32_t ins_wpo = m->clustered && cur_n <= (1u << 21) ? 1u : 0u;
+    hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                       m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, kout, ins_wpo);
     // prep over the survivors: no list, x and y are the high and the low word of the packed keys
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
@@ -1340,7 +1342,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     if (nd == 0) break;
     // clustered tables found out HERE (the rule of run_write's rounds): the growth rounds that follow move their big rows in two
     // passes, and the batches that follow start with the hint table and the at-home bitmaps in place: first two steps of the dense-id
-    // stream 139 + 37 -> 118 + 15 ms (what is left of the first: the hot rows' new keys queue at one front per run, k_insert_keys)
+    // stream 139 + 37 -> 90 + 15 ms with the wave per key below (what is left of the first: the hot rows' new keys queue at one front per run)
     if (!m->clustered_forced && !m->clustered && (uint64_t)c.n_long_ops * 64 >= cur_n) {
       m->clustered = true; m->clustered_quiet = 0;
       clustered_sync(m, s);
