@@ -531,6 +531,8 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
   for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {                 // block-uniform
     const GrowTask k = tasks[list[li]];
     if (k.new_base == 0 || grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE || !rest_by_lds(k)) continue;
+    const long long d_t0 = dbg ? clock64() : 0;
+    long long d_place = 0;
     const uint32_t old_size = 1u << k.old_lg, omask = old_size - 1u, new_size = 2u * old_size, nmask = new_size - 1u, nw = new_size >> 6;
     const uint64_t* O = row_cells(arena, k.old_base);
     uint64_t* T = row_cells(arena, k.new_base);
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
     }
     __syncthreads();
     const uint32_t lo = bound[wave], hi = bound[wave + 1];
+    const long long d_t1 = dbg ? clock64() : 0;
     // A table whose first run continues its last one round the end (wrapped cells: GrowTask::wrap_from): the wrapped cells sit
     // in the FIRST piece and come first in old slot order, but land among the cells of the LAST piece -- so the wave that holds
     // the end of the table starts only when wave 0 is through (bound[REST_WAVES + 1]); all other pieces stay independent.
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
     uint32_t d_steps = 0, d_rounds = 0, d_trips = 0;
     // a step: the first `cnt` staged cells (cnt <= 64), lane l = the l-th of them in old slot order
     auto place = [&](uint32_t cnt) {
+      const long long d_p0 = dbg ? clock64() : 0;
       const bool valid = lane < cnt;
       const uint64_t cell = valid ? stage[lane] : 0ull;                     // {key, priority}
       uint32_t cur = cell_key(cell) & nmask;
@@ -667,6 +671,7 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
       for (uint32_t q = 0; q < (REST_STAGE + 63) / 64; q++) if (q * 64 + lane < rest) stage[q * 64 + lane] = mv[q];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       n_st = rest;
+      if (dbg) d_place += clock64() - d_p0;
     };
     // the range, eight chunks of 64 old slots per trip (their loads in flight together), staged four at a time
     for (uint32_t p0 = lo; p0 < hi; p0 += 512) {                             // (wave-uniform)
@@ -698,6 +703,11 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
       atomicAdd(&dbg[0], (unsigned long long)d_steps); atomicAdd(&dbg[1], (unsigned long long)d_rounds);
       atomicMax(&dbg[3], (unsigned long long)d_steps); atomicAdd(&dbg[4], (unsigned long long)d_trips); atomicMax(&dbg[5], (unsigned long long)d_trips);
       atomicMax(&dbg[6], (unsigned long long)d_rounds);
+      const long long d_t2 = clock64();                                     // (clock ticks: the longest row, its set-up, its longest wave, the placing in it; sums for the averages)
+      atomicMax(&dbg[50], (unsigned long long)(d_t2 - d_t0)); atomicMax(&dbg[51], (unsigned long long)(d_t1 - d_t0));
+      atomicMax(&dbg[52], (unsigned long long)(d_t2 - d_t1)); atomicMax(&dbg[53], (unsigned long long)d_place);
+      atomicAdd(&dbg[54], (unsigned long long)(d_t2 - d_t1)); atomicAdd(&dbg[55], (unsigned long long)d_place); atomicAdd(&dbg[56], 1ull);
+      if (wave == 0) atomicMax(&dbg[64 + ((dbg_mode >> 8) & 31u)], ((unsigned long long)((d_t2 - d_t0) >> 10) << 40) | ((unsigned long long)((d_t1 - d_t0) >> 10) << 20) | (unsigned long long)k.old_lg);
     }
   }
 }

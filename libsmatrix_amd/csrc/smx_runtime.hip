@@ -667,7 +667,7 @@ struct Matrix {
   uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
   bool retry_split = true;              // SMATRIX_RETRY_SPLIT=0: the retry of a clustered table a wave per op in one launch
   bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
-  unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
+  unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0; uint64_t rest_dbg_from = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
   void* host_pipe = nullptr;            // HostPipe: the staging of large host-pointer batches (smatrix_apply_batch and friends)
   // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
@@ -1068,7 +1068,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
       // takes only what that kernel leaves (giant rows, rows with wrapped cells).  SMATRIX_REST_LDS=0: the chunked pass alone
       if (m->rest_lds)
         hipLaunchKernelGGL(k_grow_rest_lds, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 1024)), dim3(REST_THREADS), rest_lds_bytes(), sc,
-                           m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->arena.base, m->rest_dbg, m->rest_dbg_mode);
+                           m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->arena.base, m->st.batches >= m->rest_dbg_from ? m->rest_dbg : nullptr, m->rest_dbg_mode | ((uint32_t)(m->st.batches & 31u) << 8));
       hipLaunchKernelGGL(k_grow_move_rest, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                          dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, m->rest_lds);
     } else {
@@ -2230,10 +2230,11 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
   if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
   if (const char* a = getenv("SMATRIX_RETRY_SPLIT")) m->retry_split = *a != '0';
+  if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters of k_grow_rest_lds from this batch on)
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
-    dev_malloc(&m->rest_dbg, 512);
-    HIP_OK(hipMemset(m->rest_dbg, 0, 512));
+    dev_malloc(&m->rest_dbg, 1024);
+    HIP_OK(hipMemset(m->rest_dbg, 0, 1024));
     HIP_OK(hipMemcpy(m->arena.base + offsetof(ArenaHead, dbg), &m->rest_dbg, 8, hipMemcpyHostToDevice));
   }
   if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
@@ -2282,8 +2283,8 @@ void smatrix_close(smatrix_t* self) {
   if (m) {
     set_device(m);
     if (m->rest_dbg) {
-      unsigned long long c[64];
-      HIP_OK(hipMemcpy(c, m->rest_dbg, 512, hipMemcpyDeviceToHost));
+      unsigned long long c[128];
+      HIP_OK(hipMemcpy(c, m->rest_dbg, 1024, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smatrix] far join, long probes of the wave-per-op pass: not in the table %llu, cell known %llu, absent at the scan %llu\n", c[16], c[17], c[18]);
       if (c[40] && m->far_lanes) fprintf(stderr, "[smatrix] far_walk: %llu walks, %.0f cells on average, longest %llu; by row size 2^(4k..): %llu %llu %llu %llu %llu %llu\n", c[40], c[41] / (double)c[40], c[42],
                          c[43], c[44], c[45], c[46], c[47], c[48]);
@@ -2296,6 +2297,9 @@ void smatrix_close(smatrix_t* self) {
                                           c[40] / (double)c[28], c[41] / (double)c[28], c[42] / (double)c[28], c[43] / (double)c[28]);
       fprintf(stderr, "[smatrix] k_grow_rest_lds: steps %llu rounds %llu | most steps of a wave %llu, most rounds %llu | trips %llu, most of a wave %llu | per round: losers %.2f blocked %.2f committed %.2f\n",
               c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
+      fprintf(stderr, "[smatrix] k_grow_rest_lds clock ticks, longest of all launches: row %llu = set-up %llu + waves %llu (placing %llu); a wave on average: %.0f (placing %.0f) over %llu waves\n",
+              c[50], c[51], c[52], c[53], c[54] / (double)std::max(1ull, c[56]), c[55] / (double)std::max(1ull, c[56]), c[56]);
+      for (int i = 0; i < 32; i++) if (c[64 + i]) fprintf(stderr, "[smatrix]   batch %%32 == %d: the row wave 0 of which ran longest: %llu k ticks, set-up %llu k, old table 2^%llu\n", i, c[64 + i] >> 40, (c[64 + i] >> 20) & 0xFFFFF, c[64 + i] & 0xFF);
       (void)hipFree(m->rest_dbg);
     }
     if (m->flusher.joinable()) {                       // (it may be inside a flush: close waits for it, then does the last one)
