@@ -849,11 +849,26 @@ constexpr uint32_t INS_THREADS = 1024;
 // wpo (round 5, clustered tables): a WAVE per key -- lane 0 holds it, the wave finishes its long probe, as in k_apply_wpo.  The late
 // rounds of a dense-id cold start are a few 10^5 keys of the hottest rows, every one a walk to the end of a long run: a lane per key,
 // a wave took its 64 walks one after the other (8, 16, 30, 49 ms for the last four rounds of the stream's first batch).
+// mode (round 5, clustered tables): the order in which a batch's new keys go in is the library's to choose (any order is one the
+// reference's threads could have taken), and the identity hash rewards ONE order: a key below the table's size sits at home
+// whatever else is in, as long as no key that wraps (y >= size) got there first.  So a cold round runs twice over its keys:
+//   INS_SMALL_ONLY  keys below their row's size whose home cell is free only (one compare-and-swap, no walk); the others stay listed;
+//   INS_HOME_ONLY   then, over what that left (INS_FROM_PREV: ctl->n_prev keys, k_list_advance): any key whose home cell is free -- rows
+//                   the first launch filled to their threshold refuse by the snapshot, so only rows that ran out of small keys
+//                   take wrapping ones, and first those that need no walk (the hottest row of the dense stream's first batch has
+//                   180 000 keys below 2^19 and must hold 262 145 before it may double again: 82 000 of its 120 000 larger keys
+//                   go in at that size, and more than half of them find their home cell free);
+//   (neither)       last, over what is left, everything admitted: the walks, a wave per key.
+// A dense-id row then grows through all its doublings with (next to) no displaced cell -- its 10^5 new keys used to go in in list
+// order, most of them wrapped onto the run of the keys before them and queued at its end, round after round, and every doubling
+// moved them again: rounds 6-10 of the dense stream's first batch took 4.5 + 6.4 + 10.7 + 17.6 + 19.3 ms.
+constexpr uint32_t INS_SMALL_ONLY = 1u, INS_FROM_PREV = 2u, INS_HOME_ONLY = 4u;
 __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
-    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const unsigned long long* __restrict__ kin,
-    unsigned long long* __restrict__ kout, uint32_t wpo) {
+    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_host, const unsigned long long* __restrict__ kin,
+    unsigned long long* __restrict__ kout, uint32_t wpo, uint32_t mode) {
   __shared__ uint32_t l_row[2 * INS_THREADS], l_cnt[2 * INS_THREADS], l_grant[2 * INS_THREADS];
   __shared__ uint32_t l_n, l_base;
+  const uint32_t n = (mode & INS_FROM_PREV) ? min(n_host, aload(&ctl->n_prev)) : n_host;     // (uniform)
   const uint64_t n_lanes = wpo ? (uint64_t)n * 64u : (uint64_t)n;
   const uint32_t lane_budget = wpo ? 4u : PROBE_BUDGET;
   for (uint64_t t064 = (uint64_t)blockIdx.x * INS_THREADS; t064 < n_lanes; t064 += (uint64_t)gridDim.x * INS_THREADS) {   // block-uniform
@@ -882,6 +897,8 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
         // "every share is used up" mark: the key is absent (listed keys are), so it is deferred WITHOUT walking to its empty
         // cell first.  Three quarters of a cold round's keys belong to rows that are waiting for their doubling.
         deferred = true;
+      } else if ((mode & INS_SMALL_ONLY) && Y > ((1u << meta_lg(s.x)) - 1u)) {
+        deferred = true;                                         // (a key that wraps: the second launch of the round)
       } else {
         mask = (1u << meta_lg(s.x)) - 1u;
         cells = row_cells(arena, s.z);
@@ -891,6 +908,7 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
           const uint64_t c = cells[pos];
           if (cell_key(c) == Y) break;                           // it exists: nothing to do
           if (c == 0) { need = true; break; }
+          if (mode & (INS_SMALL_ONLY | INS_HOME_ONLY)) { deferred = true; break; }     // (its home cell holds another key: a walk, the last launch's)
           if (steps > lane_budget) { general = true; break; }
           pos = (pos + 1) & mask;
         }
@@ -986,10 +1004,13 @@ constexpr uint32_t DEDUP_THREADS = 1024, DEDUP_TRIPS = 8;
 __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ xs,
                                                              const uint32_t* __restrict__ ys, uint32_t st, unsigned long long* set,
                                                              uint64_t set_mask, unsigned long long* reps, uint32_t* n_reps) {
+  // n_reps[1]: how many of the distinct keys have y < n (the length of the list).  Dense ids -- the ids of a batch about as many as
+  // its keys -- put nearly all of them there, scrambled or hashed ids one in 2^32 / n: the host's evidence for taking the keys of
+  // the cold rounds smallest first (k_insert_keys: mode) before a single long probe has been seen.
   __shared__ unsigned long long l_rep[DEDUP_THREADS * DEDUP_TRIPS];     // (round 4: the distinct keys themselves, x << 32 | y)
-  __shared__ uint32_t l_n, l_base;
+  __shared__ uint32_t l_n, l_base, l_small;
   for (uint64_t b0 = (uint64_t)blockIdx.x * DEDUP_THREADS * DEDUP_TRIPS; b0 < n; b0 += (uint64_t)gridDim.x * DEDUP_THREADS * DEDUP_TRIPS) {
-    if (threadIdx.x == 0) l_n = 0;
+    if (threadIdx.x == 0) { l_n = 0; l_small = 0; }
     __syncthreads();
     for (uint32_t k = 0; k < DEDUP_TRIPS; k++) {
       const uint64_t t = b0 + (uint64_t)k * DEDUP_THREADS + threadIdx.x;
@@ -1013,13 +1034,15 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
         }
       }
       const uint64_t wm = __ballot(won);
+      const uint64_t sm = __ballot(won && (uint32_t)key < n);
       uint32_t wb = 0;
+      if (sm && __lane_id() == 0) atomicAdd(&l_small, (uint32_t)__popcll(sm));
       if (wm && __lane_id() == 0) wb = atomicAdd(&l_n, (uint32_t)__popcll(wm));
       wb = __shfl(wb, 0);
       if (won) l_rep[wb + (uint32_t)__popcll(wm & ((1ull << __lane_id()) - 1ull))] = key;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && l_n) l_base = atomicAdd(n_reps, l_n);
+    if (threadIdx.x == 0 && l_n) { l_base = atomicAdd(n_reps, l_n); if (l_small) atomicAdd(n_reps + 1, l_small); }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < l_n; i += DEDUP_THREADS) reps[l_base + i] = l_rep[i];
     __syncthreads();

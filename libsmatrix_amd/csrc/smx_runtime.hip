@@ -665,6 +665,7 @@ struct Matrix {
   uint32_t hint_lg = 22;
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
+  bool small_first = true;              // SMATRIX_SMALL_FIRST=0: the cold rounds of a clustered table take their keys in list order (one launch per round)
   bool retry_split = true;              // SMATRIX_RETRY_SPLIT=0: the retry of a clustered table a wave per op in one launch
   bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0; uint64_t rest_dbg_from = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
@@ -1287,21 +1288,24 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   m->cold_set.need_on(slots, s);
   m->cold_keys[0].need_on(n_list, s);
   zero_async(m->cold_set.p, slots * 8, s);
-  HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 4, s));      // (words 0..9 of the scratch belong to the scalar path and the partition)
+  HIP_OK(hipMemsetAsync(m->d_small + 12, 0, 8, s));      // (words 0..9 of the scratch belong to the scalar path and the partition)
   hipLaunchKernelGGL(k_dedup_keys, dim3(std::min<uint32_t>(blocks_for(n_list, DEDUP_THREADS * DEDUP_TRIPS), 4096)), dim3(DEDUP_THREADS), 0, s,
                      n_list, list, x, y, m->in_stride, m->cold_set.p, slots - 1, m->cold_keys[0].p, m->d_small + 12);
   HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 8, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   uint32_t cur_n = m->h_small[12];
+  // dense ids: a quarter of the distinct keys below the length of the list (scrambled ids: one in 2^32 / n_list)
+  const bool dense_keys = (uint64_t)m->h_small[13] * 4 >= cur_n;
   if (m->trace_rounds)
-    fprintf(stderr, "[smatrix] batch %llu cold start: %u pending ops name %u distinct keys\n", (unsigned long long)m->st.batches, n_list, cur_n);
+    fprintf(stderr, "[smatrix] batch %llu cold start: %u pending ops name %u distinct keys, %u of them below %u%s\n", (unsigned long long)m->st.batches, n_list, cur_n,
+            m->h_small[13], n_list, dense_keys && m->small_first ? ": the rounds take the keys below their row's size first" : "");
   if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) return false;      // (the scratch stays while the table is young: run_write)
   m->st.cold_starts++;
   m->st.cold_keys += cur_n;
   // 2. the rounds, over the keys (packed, x << 32 | y: every round streams its input and writes what stays deferred the same way)
   const unsigned long long* kin = m->cold_keys[0].p;
-  uint32_t stalled = 0, rows_before = m->dir_used;
+  uint32_t stalled = 0, rows_before = m->dir_used, cur_buf = 0;        // (cur_buf: which of the two buffers holds the round's input)
   for (uint32_t round = 0; cur_n; round++) {
     if (stalled > 8) smx_die("write batch did not converge (corrupt row table?)");
     const uint32_t dir_limit = m->dir_size / 2;
@@ -1311,13 +1315,30 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     m->klist.need(4 * (size_t)m->klist_cap);
     m->rebal.need(std::min<uint64_t>(cur_n, m->dir_size));
     // (two buffers take turns: the dedup's output, sized for the whole list, and one for the first round's survivors)
-    unsigned long long* kout = (round & 1) ? m->cold_keys[0].p : (m->cold_keys[1].need_on(cur_n, s), m->cold_keys[1].p);
+    unsigned long long* other = cur_buf ? m->cold_keys[0].p : (m->cold_keys[1].need_on(cur_n, s), m->cold_keys[1].p);
     ensure_arena_free(m, std::min<uint64_t>(cur_n, room), s);
     ctl_reset_round(m, s);
     // (clustered tables, lists up to 2^21 keys: a wave per key -- k_insert_keys)
     const uint32_t ins_wpo = m->clustered && cur_n <= (1u << 21) ? 1u : 0u;
-    hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
-                       m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, kout, ins_wpo);
+    unsigned long long* kout = other;
+    if ((m->clustered || dense_keys) && m->small_first) {
+      // clustered tables / dense ids: the keys below their row's size first, then any key whose home cell is free, then the walks
+      // over what is left (k_insert_keys: mode) -- the launches write the two buffers in turn
+      unsigned long long* mine = const_cast<unsigned long long*>(kin);
+      hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, other, 0u, INS_SMALL_ONLY);
+      hipLaunchKernelGGL(k_list_advance, dim3(1), dim3(1), 0, s, m->d_ctl);
+      hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, other, mine, 0u, INS_HOME_ONLY | INS_FROM_PREV);
+      hipLaunchKernelGGL(k_list_advance, dim3(1), dim3(1), 0, s, m->d_ctl);
+      hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, mine, kout, ins_wpo, INS_FROM_PREV);
+      cur_buf ^= 1u;
+    } else {
+      hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, kout, ins_wpo, 0u);
+      cur_buf ^= 1u;
+    }
     // prep over the survivors: no list, x and y are the high and the low word of the packed keys
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
@@ -2230,6 +2251,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
   if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
   if (const char* a = getenv("SMATRIX_RETRY_SPLIT")) m->retry_split = *a != '0';
+  if (const char* a = getenv("SMATRIX_SMALL_FIRST")) m->small_first = *a != '0';
   if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters of k_grow_rest_lds from this batch on)
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);

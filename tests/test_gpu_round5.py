@@ -236,6 +236,53 @@ def test_dense_zipf_stream_with_and_without_the_far_join(G, oracle_mod, monkeypa
     g.close(); o.close(); gen.close()
 
 
+# ---- the cold rounds of a dense-id batch: keys below their row's size first, then free home cells, then the walks --------------------
+@pytest.mark.parametrize("small_first", ["1", "0"])
+def test_cold_start_of_dense_ids_takes_small_keys_first(G, oracle_mod, monkeypatch, small_first):
+    """A first batch of 2^21 dense Zipf ranks on 48 rows (and a second one on top): the deferred list goes through the cold start
+    (one key per distinct pair, k_dedup_keys, whose count of keys below the list's length tells dense ids from hashed ones) and its
+    rounds run three launches of k_insert_keys each -- keys below their row's size at a free home cell, any key at a free home
+    cell, the walks -- or, with SMATRIX_SMALL_FIRST=0, one launch in list order.  Whatever the order, the batch is SOME
+    serialisation of its ops: row sizes and used counters are the oracle's exactly, the cells are the oracle's as a set, and no
+    probe sequence has an empty cell inside."""
+    monkeypatch.setenv("SMATRIX_SMALL_FIRST", small_first)
+    monkeypatch.setenv("SMATRIX_COLD_MIN", "4096")
+    from libsmatrix_amd import Stream
+    gen = Stream("zipf", 4242, 1000000, 1.1, 0)
+    g, o = G(), oracle_mod.Oracle()
+    n = 1 << 21
+    x, y = gen.fill(0, 2 * n)
+    x = (x % 48).astype(np.uint32)
+    for k in range(2):
+        xs, ys = x[k * n:(k + 1) * n], y[k * n:(k + 1) * n]
+        v = np.full(n, 1 + k, np.uint32)
+        a, b = g.apply(2, xs, ys, v), o.apply(2, xs, ys, v)
+        kk = xs.astype(np.uint64) << np.uint64(32) | ys
+        assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), k
+        assert (g.apply(0, xs, ys) == o.apply(0, xs, ys)).all(), k
+    st = g.stats()
+    assert st["cold_starts"] >= 1, st
+    rows = o.list_rows()
+    assert (g.m.rowlen_batch(rows) == np.array([o.rowlen(int(r)) for r in rows], dtype=np.uint32)).all()
+    for r in rows.tolist():
+        assert g.row_info(r) == o.row_info(r), r
+        a = np.asarray(g.row_slots(r)); b = np.asarray(o.row_slots(r))
+        ka = a[(a[:, 0] != 0) | (a[:, 1] != 0)]; kb = b[(b[:, 0] != 0) | (b[:, 1] != 0)]
+        ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
+        assert ka.shape == kb.shape and (ka == kb).all(), (r, "cells")
+        ne = (a[:, 0] != 0) | (a[:, 1] != 0)
+        size = a.shape[0]
+        pos = np.flatnonzero(ne); empties = np.flatnonzero(~ne)
+        home = a[pos, 0].astype(np.int64) & (size - 1)
+        nxt = empties[np.searchsorted(empties, home) % empties.size]
+        assert (((nxt - home) % size) > ((pos - home) % size)).all(), (r, "an empty cell inside a probe sequence")
+        if small_first == "1" and size >= 4096:
+            # what the order is for: (next to) every key below the table's size sits at home
+            small = a[pos, 0].astype(np.int64) < size
+            assert (pos[small] == a[pos, 0][small]).mean() > 0.8, (r, "keys below the table's size away from home")
+    g.close(); o.close(); gen.close()
+
+
 # ---- VERDICT r4 #2: the host-pointer batch API as a three-stage pipeline ------------------------------------------------------
 def test_large_host_batches_run_in_chunks_like_one_call(G, oracle_mod, monkeypatch):
     """smatrix_apply_batch / smatrix_rowlen_batch with arrays above two chunks stage the caller's memory through pinned buffers
