@@ -997,6 +997,16 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
   }
 }
 
+// The walks of a cold round through the batch's far join (insert_pending_keys): the packed keys are handed to k_apply_wpo_far as ops
+// -- x and y are the high and the low word of a key (stride 2), the amounts a zeroed array, the list 0..n-1 -- and the indices it
+// leaves deferred are turned back into packed keys for prep and the next round.
+__global__ void k_iota(uint32_t* out, uint32_t n);           // (defined below: the list 0..n-1)
+__global__ __launch_bounds__(256) void k_gather_keys(const Ctl* ctl, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ kin,
+                                                     unsigned long long* __restrict__ kout, uint32_t n_max) {
+  const uint32_t n = min(aload(&ctl->n_defer), n_max);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) kout[i] = kin[idx[i]];
+}
+
 // One representative op per distinct key (x, y != 0) among the listed ops: a scratch hash set of 64-bit keys (zeroed by the
 // caller, >= 2 slots per op), the first op to claim a key goes to `reps`.  Representatives are collected in LDS and leave
 // with ONE reservation per workgroup and DEDUP_TRIPS x 1024 ops (a reservation per wave queued 10^5 atomics on one word).

@@ -688,6 +688,9 @@ struct Matrix {
                                         // first chunk of the CF import has 3 M of 2^25 ops pending when its rows have been created, and needs it:
                                         // 0.036 against 0.126 s.  The price is 0.12 ms of de-duplication that finds nothing in batch 2 of config 2.)
   DevBuf<unsigned long long> cold_set;
+  DevBuf<uint32_t> cold_idx[2], cold_zero;   // the walks of a cold round through the far join: the list 0..n-1, what the pass leaves, zeroed amounts
+  uint32_t cold_far_max = 1u << 20;     // ... for lists up to this many keys (SMATRIX_COLD_FAR_MAX): the early rounds' millions of keys sit in small rows, a lane walks them faster
+  bool cold_far = true;                 // SMATRIX_COLD_FAR=0: the walks of a clustered table's cold rounds a wave per key (k_insert_keys)
   DevBuf<unsigned long long> cold_keys[2];   // the distinct pending keys, packed; what a round leaves deferred
 };
 
@@ -1303,6 +1306,14 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   if ((uint64_t)cur_n * 4 > (uint64_t)n_list * 3) return false;      // (the scratch stays while the table is young: run_write)
   m->st.cold_starts++;
   m->st.cold_keys += cur_n;
+  // dense ids ARE clustered tables as soon as rows are big: the mode is switched on here (hint table, at-home bitmaps, two-pass growth
+  // of big rows, the walks of the rounds below by the far join) instead of after the first rounds full of long probes -- with the
+  // keys below a row's size going in first there are few of those to see (the mode goes again when batches stay quiet: run_write)
+  if (dense_keys && m->small_first && !m->clustered_forced && !m->clustered) {
+    m->clustered = true; m->clustered_quiet = 0;
+    clustered_sync(m, s);
+    if (m->trace_rounds) fprintf(stderr, "[smatrix]   dense ids: clustered tables from here on\n");
+  }
   // 2. the rounds, over the keys (packed, x << 32 | y: every round streams its input and writes what stays deferred the same way)
   const unsigned long long* kin = m->cold_keys[0].p;
   uint32_t stalled = 0, rows_before = m->dir_used, cur_buf = 0;        // (cur_buf: which of the two buffers holds the round's input)
@@ -1331,8 +1342,31 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
       hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
                          m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, other, mine, 0u, INS_HOME_ONLY | INS_FROM_PREV);
       hipLaunchKernelGGL(k_list_advance, dim3(1), dim3(1), 0, s, m->d_ctl);
-      hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
-                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, mine, kout, ins_wpo, INS_FROM_PREV);
+      bool far_joined = false;
+      if (m->clustered && m->home_on && m->far_join && m->cold_far && cur_n >= (1u << 12) && cur_n <= m->cold_far_max) {
+        // The walks by the batch's far join (the pass in front of prep of a steady batch, k_apply_wpo_far): the keys that are left
+        // are ops "incr by 0" -- x and y the two words of a packed key, the amounts a zeroed array, the list 0..n-1.  New keys CLAIM
+        // their cell by rank in the occupancy words instead of walking to the end of a run and queueing there (the wave-per-key
+        // launch took 12 + 19 + 17 ms in the last three rounds of the dense stream's first batch: a few thousand keys per hot row at
+        // ONE front, one winner per compare-and-swap).
+        m->cold_idx[0].need_on(cur_n, s); m->cold_idx[1].need_on(cur_n, s); m->cold_zero.need_on(3 * (size_t)cur_n, s);
+        zero_async(m->cold_zero.p, 8 * (size_t)cur_n, s);
+        hipLaunchKernelGGL(k_iota, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s, m->cold_idx[0].p, cur_n);
+        const uint32_t* xk = reinterpret_cast<const uint32_t*>(mine) + 1, * yk = reinterpret_cast<const uint32_t*>(mine);
+        const uint32_t stride_was = m->in_stride;
+        m->in_stride = 2;
+        far_joined = far_join_enqueue(m, s, m->cold_idx[0].p, xk, yk, cur_n);
+        if (far_joined) {
+          hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), dim3(65536), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu,
+                             m->cold_idx[0].p, xk, yk, m->cold_zero.p, m->cold_zero.p + 2 * (size_t)cur_n, m->cold_idx[1].p, 2u);     // (amounts: stride 2 like the keys, all zero; results: dense, behind them, nobody reads them)
+          arena_head_set(m, offsetof(ArenaHead, far_on), 0u, s);     // (rows are about to double: the join's view of the tables ends here)
+          hipLaunchKernelGGL(k_gather_keys, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s, m->d_ctl, m->cold_idx[1].p, mine, kout, cur_n);
+        }
+        m->in_stride = stride_was;
+      }
+      if (!far_joined)
+        hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                           m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, mine, kout, ins_wpo, INS_FROM_PREV);
       cur_buf ^= 1u;
     } else {
       hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
@@ -1736,6 +1770,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   // had the steady shape -- or at once when this batch made no use of it beyond the row count
   if (m->spec_ready || !cold_tried) {
     m->cold_set.release_on(s); m->cold_keys[0].release_on(s); m->cold_keys[1].release_on(s);
+    m->cold_idx[0].release_on(s); m->cold_idx[1].release_on(s); m->cold_zero.release_on(s);
   }
   if (m->trace_rounds) {
     AllocClock& ac = alloc_clock();
@@ -2252,6 +2287,8 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
   if (const char* a = getenv("SMATRIX_RETRY_SPLIT")) m->retry_split = *a != '0';
   if (const char* a = getenv("SMATRIX_SMALL_FIRST")) m->small_first = *a != '0';
+  if (const char* a = getenv("SMATRIX_COLD_FAR")) m->cold_far = *a != '0';
+  if (const char* a = getenv("SMATRIX_COLD_FAR_MAX")) m->cold_far_max = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters of k_grow_rest_lds from this batch on)
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
@@ -2353,6 +2390,7 @@ void smatrix_close(smatrix_t* self) {
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
       m->cold_set.release(); m->cold_keys[0].release(); m->cold_keys[1].release();
+      m->cold_idx[0].release(); m->cold_idx[1].release(); m->cold_zero.release();
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_rank.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
