@@ -858,16 +858,20 @@ constexpr uint32_t INS_THREADS = 1024;
 //                   take wrapping ones, and first those that need no walk (the hottest row of the dense stream's first batch has
 //                   180 000 keys below 2^19 and must hold 262 145 before it may double again: 82 000 of its 120 000 larger keys
 //                   go in at that size, and more than half of them find their home cell free);
-//   (neither)       last, over what is left, everything admitted: the walks, a wave per key.
+//                   a key whose home cell holds another key and whose row still has room goes into a list of its own (`kwalk`,
+//                   counted in ctl->n_absent): the WALKERS -- a fraction of what a round leaves listed, most of which waits for
+//                   its row to double;
+//   (neither)       last, over the walkers (k_walk_advance: their number becomes ctl->n_prev), everything admitted: the walks, a
+//                   wave per key -- or the batch's far join (insert_pending_keys); what stays deferred joins the round's list.
 // A dense-id row then grows through all its doublings with (next to) no displaced cell -- its 10^5 new keys used to go in in list
 // order, most of them wrapped onto the run of the keys before them and queued at its end, round after round, and every doubling
 // moved them again: rounds 6-10 of the dense stream's first batch took 4.5 + 6.4 + 10.7 + 17.6 + 19.3 ms.
 constexpr uint32_t INS_SMALL_ONLY = 1u, INS_FROM_PREV = 2u, INS_HOME_ONLY = 4u;
 __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_host, const unsigned long long* __restrict__ kin,
-    unsigned long long* __restrict__ kout, uint32_t wpo, uint32_t mode) {
+    unsigned long long* __restrict__ kout, uint32_t wpo, uint32_t mode, unsigned long long* __restrict__ kwalk) {
   __shared__ uint32_t l_row[2 * INS_THREADS], l_cnt[2 * INS_THREADS], l_grant[2 * INS_THREADS];
-  __shared__ uint32_t l_n, l_base;
+  __shared__ uint32_t l_n, l_base, l_nw, l_basew;
   const uint32_t n = (mode & INS_FROM_PREV) ? min(n_host, aload(&ctl->n_prev)) : n_host;     // (uniform)
   const uint64_t n_lanes = wpo ? (uint64_t)n * 64u : (uint64_t)n;
   const uint32_t lane_budget = wpo ? 4u : PROBE_BUDGET;
@@ -876,10 +880,10 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     const uint32_t t = wpo ? (uint32_t)(tl >> 6) : (uint32_t)tl;
     const bool live = tl < n_lanes && (!wpo || (tl & 63u) == 0);
     for (uint32_t i = threadIdx.x; i < 2 * INS_THREADS; i += INS_THREADS) { l_row[i] = 0xFFFFFFFFu; l_cnt[i] = 0; }
-    if (threadIdx.x == 0) l_n = 0;
+    if (threadIdx.x == 0) { l_n = 0; l_nw = 0; }
     unsigned long long key = 0;
     uint32_t Y = 0, pos = 0, mask = 0, e = 0, rank = 0;
-    bool deferred = false, need = false, general = false;
+    bool deferred = false, need = false, general = false, walker = false;
     uint4 s = {0, 0, 0, 0};
     DirSlot* d = nullptr;
     uint64_t* cells = nullptr;
@@ -908,7 +912,11 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
           const uint64_t c = cells[pos];
           if (cell_key(c) == Y) break;                           // it exists: nothing to do
           if (c == 0) { need = true; break; }
-          if (mode & (INS_SMALL_ONLY | INS_HOME_ONLY)) { deferred = true; break; }     // (its home cell holds another key: a walk, the last launch's)
+          if (mode & (INS_SMALL_ONLY | INS_HOME_ONLY)) {             // (its home cell holds another key: a walk, the last launch's)
+            if ((mode & INS_HOME_ONLY) && kwalk) walker = true;      // (... which takes only these: they go into a list of their own, ctl->n_absent counts them)
+            else deferred = true;
+            break;
+          }
           if (steps > lane_budget) { general = true; break; }
           pos = (pos + 1) & mask;
         }
@@ -993,6 +1001,16 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     if (threadIdx.x == 0 && l_n) l_base = atomicAdd(&ctl->n_defer, l_n);
     __syncthreads();
     if (deferred) kout[l_base + wbase + (uint32_t)__popcll(dm & ((1ull << __lane_id()) - 1ull))] = key;
+    if (kwalk) {                                                 // (uniform)
+      const uint64_t wm = __ballot(walker);
+      uint32_t wb = 0;
+      if (wm && __lane_id() == 0) wb = atomicAdd(&l_nw, (uint32_t)__popcll(wm));
+      wb = __shfl(wb, 0);
+      __syncthreads();
+      if (threadIdx.x == 0 && l_nw) l_basew = atomicAdd(&ctl->n_absent, l_nw);
+      __syncthreads();
+      if (walker) kwalk[l_basew + wb + (uint32_t)__popcll(wm & ((1ull << __lane_id()) - 1ull))] = key;
+    }
     __syncthreads();                                             // the LDS tables are reused by the next trip
   }
 }
@@ -1003,8 +1021,9 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
 __global__ void k_iota(uint32_t* out, uint32_t n);           // (defined below: the list 0..n-1)
 __global__ __launch_bounds__(256) void k_gather_keys(const Ctl* ctl, const uint32_t* __restrict__ idx, const unsigned long long* __restrict__ kin,
                                                      unsigned long long* __restrict__ kout, uint32_t n_max) {
-  const uint32_t n = min(aload(&ctl->n_defer), n_max);
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) kout[i] = kin[idx[i]];
+  // (the pass appended its indices behind the round's list: entries n_absent .. n_defer of both, see k_walk_advance)
+  const uint32_t n0 = aload(&ctl->n_absent), n = min(aload(&ctl->n_defer), n_max);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x + n0; i < n; i += (uint64_t)gridDim.x * 256) kout[i] = kin[idx[i]];
 }
 
 // One representative op per distinct key (x, y != 0) among the listed ops: a scratch hash set of 64-bit keys (zeroed by the
@@ -1097,6 +1116,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
   apply_body<OP, false, 2, false, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+}
+// a cold round's walkers become the list the last launch reads; the round's deferred list goes on behind what it holds (n_defer
+// stays), and where that was is kept in n_absent for k_gather_keys
+__global__ void k_walk_advance(Ctl* ctl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ctl->n_prev = ctl->n_absent;
+  ctl->n_absent = ctl->n_defer;
 }
 // between the two: the list the first half wrote becomes the list the second half reads (nothing else of the round's state moves)
 __global__ void k_list_advance(Ctl* ctl) {

@@ -689,9 +689,9 @@ struct Matrix {
                                         // 0.036 against 0.126 s.  The price is 0.12 ms of de-duplication that finds nothing in batch 2 of config 2.)
   DevBuf<unsigned long long> cold_set;
   DevBuf<uint32_t> cold_idx[2], cold_zero;   // the walks of a cold round through the far join: the list 0..n-1, what the pass leaves, zeroed amounts
-  uint32_t cold_far_max = 1u << 20;     // ... for lists up to this many keys (SMATRIX_COLD_FAR_MAX): the early rounds' millions of keys sit in small rows, a lane walks them faster
+  uint32_t cold_far_max = 1u << 20;     // ... in rounds of up to this many keys (SMATRIX_COLD_FAR_MAX): the early rounds' millions of keys sit in small rows, a lane walks them faster
   bool cold_far = true;                 // SMATRIX_COLD_FAR=0: the walks of a clustered table's cold rounds a wave per key (k_insert_keys)
-  DevBuf<unsigned long long> cold_keys[2];   // the distinct pending keys, packed; what a round leaves deferred
+  DevBuf<unsigned long long> cold_keys[3];   // the distinct pending keys, packed; what a round leaves deferred
 };
 
 void set_device(Matrix* m) { HIP_OK(hipSetDevice(m->device)); }
@@ -1333,26 +1333,30 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     const uint32_t ins_wpo = m->clustered && cur_n <= (1u << 21) ? 1u : 0u;
     unsigned long long* kout = other;
     if ((m->clustered || dense_keys) && m->small_first) {
-      // clustered tables / dense ids: the keys below their row's size first, then any key whose home cell is free, then the walks
-      // over what is left (k_insert_keys: mode) -- the launches write the two buffers in turn
+      // clustered tables / dense ids: the keys below their row's size first, then any key whose home cell is free -- which also
+      // sets the WALKERS aside (home cell taken, row not full) --, then the walks over those alone (k_insert_keys: mode).  The
+      // round's list ends up in its input buffer again.
       unsigned long long* mine = const_cast<unsigned long long*>(kin);
+      m->cold_keys[2].need_on(cur_n, s);
+      unsigned long long* walk = m->cold_keys[2].p;
       hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
-                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, other, 0u, INS_SMALL_ONLY);
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, other, 0u, INS_SMALL_ONLY, (unsigned long long*)nullptr);
       hipLaunchKernelGGL(k_list_advance, dim3(1), dim3(1), 0, s, m->d_ctl);
       hipLaunchKernelGGL(k_insert_keys, dim3(blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
-                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, other, mine, 0u, INS_HOME_ONLY | INS_FROM_PREV);
-      hipLaunchKernelGGL(k_list_advance, dim3(1), dim3(1), 0, s, m->d_ctl);
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, other, mine, 0u, INS_HOME_ONLY | INS_FROM_PREV, walk);
+      hipLaunchKernelGGL(k_walk_advance, dim3(1), dim3(1), 0, s, m->d_ctl);
+      kout = mine;
       bool far_joined = false;
-      if (m->clustered && m->home_on && m->far_join && m->cold_far && cur_n >= (1u << 12) && cur_n <= m->cold_far_max) {
-        // The walks by the batch's far join (the pass in front of prep of a steady batch, k_apply_wpo_far): the keys that are left
-        // are ops "incr by 0" -- x and y the two words of a packed key, the amounts a zeroed array, the list 0..n-1.  New keys CLAIM
-        // their cell by rank in the occupancy words instead of walking to the end of a run and queueing there (the wave-per-key
-        // launch took 12 + 19 + 17 ms in the last three rounds of the dense stream's first batch: a few thousand keys per hot row at
-        // ONE front, one winner per compare-and-swap).
+      if (m->clustered && m->home_on && m->far_join && m->cold_far && cur_n <= m->cold_far_max) {
+        // The walks by the batch's far join (the pass in front of prep of a steady batch, k_apply_wpo_far): the walkers are ops
+        // "incr by 0" -- x and y the two words of a packed key, the amounts a zeroed array, the list 0..n-1.  New keys CLAIM their
+        // cell by rank in the occupancy words instead of walking to the end of a run and queueing there (the wave-per-key launch
+        // took 12 + 19 + 17 ms in the last three rounds of the dense stream's first batch: a few thousand keys per hot row at ONE
+        // front, one winner per compare-and-swap).  What the pass leaves deferred it appends, as indices, behind the round's list.
         m->cold_idx[0].need_on(cur_n, s); m->cold_idx[1].need_on(cur_n, s); m->cold_zero.need_on(3 * (size_t)cur_n, s);
         zero_async(m->cold_zero.p, 8 * (size_t)cur_n, s);
         hipLaunchKernelGGL(k_iota, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s, m->cold_idx[0].p, cur_n);
-        const uint32_t* xk = reinterpret_cast<const uint32_t*>(mine) + 1, * yk = reinterpret_cast<const uint32_t*>(mine);
+        const uint32_t* xk = reinterpret_cast<const uint32_t*>(walk) + 1, * yk = reinterpret_cast<const uint32_t*>(walk);
         const uint32_t stride_was = m->in_stride;
         m->in_stride = 2;
         far_joined = far_join_enqueue(m, s, m->cold_idx[0].p, xk, yk, cur_n);
@@ -1360,17 +1364,16 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
           hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), dim3(65536), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu,
                              m->cold_idx[0].p, xk, yk, m->cold_zero.p, m->cold_zero.p + 2 * (size_t)cur_n, m->cold_idx[1].p, 2u);     // (amounts: stride 2 like the keys, all zero; results: dense, behind them, nobody reads them)
           arena_head_set(m, offsetof(ArenaHead, far_on), 0u, s);     // (rows are about to double: the join's view of the tables ends here)
-          hipLaunchKernelGGL(k_gather_keys, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s, m->d_ctl, m->cold_idx[1].p, mine, kout, cur_n);
+          hipLaunchKernelGGL(k_gather_keys, dim3(std::min<uint32_t>(blocks_for(cur_n), 4096)), dim3(256), 0, s, m->d_ctl, m->cold_idx[1].p, walk, kout, cur_n);
         }
         m->in_stride = stride_was;
       }
       if (!far_joined)
         hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
-                           m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, mine, kout, ins_wpo, INS_FROM_PREV);
-      cur_buf ^= 1u;
+                           m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, walk, kout, ins_wpo, INS_FROM_PREV, (unsigned long long*)nullptr);
     } else {
       hipLaunchKernelGGL(k_insert_keys, dim3(ins_wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
-                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, kout, ins_wpo, 0u);
+                         m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, kin, kout, ins_wpo, 0u, (unsigned long long*)nullptr);
       cur_buf ^= 1u;
     }
     // prep over the survivors: no list, x and y are the high and the low word of the packed keys
@@ -1769,7 +1772,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
   // the cold start's scratch (and the key set the bulk path's row count may have left behind) goes back once a batch has
   // had the steady shape -- or at once when this batch made no use of it beyond the row count
   if (m->spec_ready || !cold_tried) {
-    m->cold_set.release_on(s); m->cold_keys[0].release_on(s); m->cold_keys[1].release_on(s);
+    m->cold_set.release_on(s); m->cold_keys[0].release_on(s); m->cold_keys[1].release_on(s); m->cold_keys[2].release_on(s);
     m->cold_idx[0].release_on(s); m->cold_idx[1].release_on(s); m->cold_zero.release_on(s);
   }
   if (m->trace_rounds) {
@@ -2389,7 +2392,7 @@ void smatrix_close(smatrix_t* self) {
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
-      m->cold_set.release(); m->cold_keys[0].release(); m->cold_keys[1].release();
+      m->cold_set.release(); m->cold_keys[0].release(); m->cold_keys[1].release(); m->cold_keys[2].release();
       m->cold_idx[0].release(); m->cold_idx[1].release(); m->cold_zero.release();
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_rank.release(); m->fx_excl.release(); m->fx_tiles.release();
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
