@@ -103,6 +103,7 @@ def short_line(full, detail_path=None):
     summ = {"sustained_ms_per_step_median_group": g(full, "sustained", "ms_per_step_median_group"),
             "matches_reference_checksums": g(full, "reference_checksums", "matches_reference"),
             "dense_ids_Mops_per_s": g(full, "dense_ids", "Mops_per_s"),
+            "dense_ids_first_step_ms": g(full, "dense_ids", "first_step_ms"),
             "dense_ids_matches_reference": g(full, "dense_ids", "matches_reference"),
             "roofline_dense": _pick(g(full, "dense_ids", "roofline_dense") or {}, "kernel", "avg_launch_ms", "traffic", "r04_fetch_bytes", "achieved", "frac"),
             "op_kinds_Gops_per_s": g(full, "op_kinds", "Gops_per_s"),
@@ -851,12 +852,17 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
     o1 = torch.empty(B, dtype=torch.int32, device=dev); o2 = torch.empty_like(o1)
     warm = 2
     m.profile(True)
+    first_ms = None
     for k in range(steps):
         if k == warm:
             m.profile(True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
+        if k == 0:
+            torch.cuda.synchronize(); tf = time.perf_counter()
         m.apply_batch_dev(OP_INCR, B, xs[k].data_ptr(), ys[k].data_ptr(), ones.data_ptr(), o1.data_ptr(), stream)
         m.apply_batch_dev(OP_GET, B, xs[k].data_ptr(), ys[k].data_ptr(), None, o2.data_ptr(), stream)
+        if k == 0:
+            torch.cuda.synchronize(); first_ms = (time.perf_counter() - tf) * 1e3      # (the cold start of a dense-id matrix: every row created, the keys of the hot rows in their best order)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = m.stats()
@@ -900,7 +906,7 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
             rd["frac"] = rd["achieved"] / HBM_PEAK_GBS
     except Exception:
         rd = None
-    return {"steps": n, "ms_per_step": dt / n * 1e3, "Mops_per_s": 2 * B * n / dt / 1e6, "rows": int(st["rows"]), "roofline_dense": rd,
+    return {"steps": n, "ms_per_step": dt / n * 1e3, "Mops_per_s": 2 * B * n / dt / 1e6, "first_step_ms": first_ms, "rows": int(st["rows"]), "roofline_dense": rd,
             "incr_kernel_ms": st["kernel_ms_incr"] / max(st["kernel_launches_incr"], 1),
             "get_kernel_ms": st["kernel_ms_get"] / max(st["kernel_launches_get"], 1), "sanity": ok,
             "at_4e8_ops": got, "matches_reference": None if got is None else all(got[k] == ref[k] for k in ref),

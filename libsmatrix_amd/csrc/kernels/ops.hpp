@@ -866,7 +866,13 @@ constexpr uint32_t INS_THREADS = 1024;
 // A dense-id row then grows through all its doublings with (next to) no displaced cell -- its 10^5 new keys used to go in in list
 // order, most of them wrapped onto the run of the keys before them and queued at its end, round after round, and every doubling
 // moved them again: rounds 6-10 of the dense stream's first batch took 4.5 + 6.4 + 10.7 + 17.6 + 19.3 ms.
-constexpr uint32_t INS_SMALL_ONLY = 1u, INS_FROM_PREV = 2u, INS_HOME_ONLY = 4u;
+// INS_DROP_EXISTING: nothing is inserted -- every key is looked for (the whole probe, the wave's cooperative one where it is long), a
+// key that EXISTS leaves the list, the others stay.  The rounds below and their prep take a listed key for absent (a row at its
+// threshold defers without a look, prep grows it without one); that holds for what the op kernels defer, but not for what the
+// pass in front of prep of a clustered table leaves: of two ops that name one new far key one claims and inserts it, the other
+// waits for the retry -- its key is in the table by the time the cold start reads the list (a row that ended a batch at exactly
+// size/2 + 1 keys was doubled for a key it already held: tests/cold_soak.py, seed 12).
+constexpr uint32_t INS_SMALL_ONLY = 1u, INS_FROM_PREV = 2u, INS_HOME_ONLY = 4u, INS_DROP_EXISTING = 8u;
 __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n_host, const unsigned long long* __restrict__ kin,
     unsigned long long* __restrict__ kout, uint32_t wpo, uint32_t mode, unsigned long long* __restrict__ kwalk) {
@@ -894,7 +900,19 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
       Y = (uint32_t)key;
       d = dir_find(dir, dmask, (uint32_t)(key >> 32), &s);
       if (!d || s.z == 0) deferred = true;                       // the row does not exist (yet): prep creates it
-      else if (Y == 0) general = true;
+      else if (Y == 0) general = !(mode & INS_DROP_EXISTING), deferred = (mode & INS_DROP_EXISTING) != 0;
+      else if (mode & INS_DROP_EXISTING) {
+        mask = (1u << meta_lg(s.x)) - 1u;
+        cells = row_cells(arena, s.z);
+        pos = Y & mask;
+        for (uint32_t steps = 0;; steps++) {
+          const uint64_t c = cells[pos];
+          if (cell_key(c) == Y) break;                           // it exists: it leaves the list
+          if (c == 0) { deferred = true; break; }                // absent: it stays
+          if (steps > lane_budget) { lp = LongProbe{true, cells, mask, pos}; break; }
+          pos = (pos + 1) & mask;
+        }
+      }
       else if (meta_lg(s.x) < BIG_LG ? s.w > (1u << meta_lg(s.x)) / 2u
                                      : __hip_atomic_load(&row_subs(arena, s.z, meta_lg(s.x))[0].pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         // (round 4) the row stands at the reference's threshold (src/smatrix.c:346) -- the snapshot's count, or a big row's
@@ -988,6 +1006,7 @@ __global__ __launch_bounds__(INS_THREADS) void k_insert_keys(
       if (lp.need) {
         lp.need = false;
         if (p == PROBE_NONE) deferred = true;
+        else if (mode & INS_DROP_EXISTING) deferred = cell_key(lp.cells[p]) != Y;      // (the probe ended on the key, or on an empty cell)
         else r = apply_row<OP_INCR, true, 1>(d, s, arena, Y, 0u, p, &deferred, &lp);
       }
     }

@@ -207,7 +207,10 @@ __device__ __forceinline__ void prep_body(
       if (lp.need && ah->far_on && !ah->twins) {
         const FarHit fh = far_find(arena, lp.cells, Y);
         if (fh.state == FAR_FOUND && cell_key(lp.cells[fh.slot]) == Y) { absent = false; lp.need = false; }
-        else if (fh.state == FAR_ABSENT) occ = fh.occ;
+        // (the words AS SCANNED, not the live ones: a claimed insert marks its cell in the live words, and a probe by those steps
+        //  over it -- the second op of a key that another op of the pass claimed and inserted found the key "absent" here, and a
+        //  row that ended the batch at exactly size/2 + 1 keys was doubled for a key it held: tests/cold_soak.py, seed 12)
+        else if (fh.state == FAR_ABSENT) occ = ah->far_occ0 + (fh.occ - ah->far_occ);
       }
     }
     while (__any(lp.need)) {                        // long sequences (dense ids): the wave finishes them (coop_probe)

@@ -665,6 +665,7 @@ struct Matrix {
   uint32_t hint_lg = 22;
   uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
   uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
+  bool retry_far = true;                // SMATRIX_RETRY_FAR=0: the long retry lists of a clustered table in host-driven rounds a wave per op without the far join
   bool small_first = true;              // SMATRIX_SMALL_FIRST=0: the cold rounds of a clustered table take their keys in list order (one launch per round)
   bool retry_split = true;              // SMATRIX_RETRY_SPLIT=0: the retry of a clustered table a wave per op in one launch
   bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
@@ -903,6 +904,21 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
 template <int OP>
 void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, const uint32_t* x,
                   const uint32_t* y, const uint32_t* v, uint32_t* out, uint32_t* defer) {
+  if ((OP == OP_INCR || OP == OP_DECR) && idx && m->clustered && m->retry_far && n >= (1u << 15) && n <= (1u << 21) && m->in_stride != 3) {
+    // a long retry list of a clustered table in a round the host drives (the young table's batches: rows that double twice leave
+    // 10^5 ops for a third round, most of them new keys that wrap onto the runs of the hot rows): through the batch's far join,
+    // rebuilt for this list -- claimed inserts by rank instead of a queue at one front per run.  (Measured and rejected as #51
+    // while a claim could take a hundred turns; with claims by rank: rounds of 6.7 and 4.2 ms in the dense stream's second and
+    // third batch.)
+    HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&m->d_ctl->n_prev), (int)n, 1, s));      // (the join's kernels read the list's length there)
+    if (far_join_enqueue(m, s, idx, x, y, n)) {
+      hipLaunchKernelGGL((k_apply_wpo_far<OP == OP_DECR ? OP_DECR : OP_INCR>), dim3(65536), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, n,
+                         idx, x, y, v, out, defer, m->in_stride);
+      HIP_OK(hipGetLastError());
+      arena_head_set(m, offsetof(ArenaHead, far_on), 0u, s);
+      return;
+    }
+  }
   if (OP != OP_GET && idx && m->clustered && n <= m->wpo_max) {
     // a retry list of a clustered table: a wave per op (k_apply_wpo)
     hipLaunchKernelGGL((k_apply_wpo<OP>), dim3(std::min<uint32_t>(blocks_for((uint64_t)n * 64), 65536)), dim3(256), 0, s, m->d_ctl, m->d_dir,
@@ -1251,7 +1267,11 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
       while (slots < 2ull * nd) slots <<= 1;
       m->cold_set.need_on(slots, s);
       m->cold_keys[0].need_on(nd, s);
-      m->cold_keys[1].need_on(nd / 4, s);               // (what the first round leaves: usually a quarter of the list names distinct keys)
+      m->cold_keys[1].need_on(nd / 4 + nd / 8, s);      // (what the first round leaves: usually a quarter of the list names distinct keys)
+      if (m->small_first) m->cold_keys[2].need_on(nd / 4 + nd / 8, s);     // (dense ids: the walkers' list; the far join's index lists and zeroed amounts)
+      if (m->small_first && m->cold_far && m->far_join) {
+        m->cold_idx[0].need_on(m->cold_far_max, s); m->cold_idx[1].need_on(m->cold_far_max, s); m->cold_zero.need_on(3 * (size_t)m->cold_far_max, s);
+      }
     }
   }
   ctl_read(m, s);
@@ -1311,14 +1331,31 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
   // dense ids ARE clustered tables as soon as rows are big: the mode is switched on here (hint table, at-home bitmaps, two-pass growth
   // of big rows, the walks of the rounds below by the far join) instead of after the first rounds full of long probes -- with the
   // keys below a row's size going in first there are few of those to see (the mode goes again when batches stay quiet: run_write)
+  const bool was_clustered = m->clustered;      // (... when this batch's op rounds ran)
   if (dense_keys && m->small_first && !m->clustered_forced && !m->clustered) {
     m->clustered = true; m->clustered_quiet = 0;
     clustered_sync(m, s);
     if (m->trace_rounds) fprintf(stderr, "[smatrix]   dense ids: clustered tables from here on\n");
   }
+  // a clustered table: the list may name keys that EXIST (what the pass in front of prep left for the retry: k_insert_keys,
+  // INS_DROP_EXISTING) -- they leave it here, once, before the rounds that take every listed key for absent
+  uint32_t cur_buf = 0;                                                // (which of the two buffers holds the round's input)
+  if (was_clustered && m->dir_used) {
+    m->cold_keys[1].need_on(cur_n, s);
+    ctl_reset_round(m, s);
+    const uint32_t wpo = cur_n <= (1u << 21) ? 1u : 0u;
+    hipLaunchKernelGGL(k_insert_keys, dim3(wpo ? std::min<uint32_t>(blocks_for((uint64_t)cur_n * 64, INS_THREADS), 16384) : blocks_for(cur_n, INS_THREADS)), dim3(INS_THREADS), 0, s,
+                       m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, cur_n, m->cold_keys[0].p, m->cold_keys[1].p, wpo, INS_DROP_EXISTING, (unsigned long long*)nullptr);
+    HIP_OK(hipGetLastError());
+    ctl_read(m, s);
+    if (m->trace_rounds) fprintf(stderr, "[smatrix]   %u of the %u keys exist already (left by the pass in front of prep): dropped from the list\n", cur_n - m->h_ctl->n_defer, cur_n);
+    cur_n = m->h_ctl->n_defer;
+    cur_buf = 1;
+    if (cur_n == 0) return true;
+  }
   // 2. the rounds, over the keys (packed, x << 32 | y: every round streams its input and writes what stays deferred the same way)
-  const unsigned long long* kin = m->cold_keys[0].p;
-  uint32_t stalled = 0, rows_before = m->dir_used, cur_buf = 0;        // (cur_buf: which of the two buffers holds the round's input)
+  const unsigned long long* kin = m->cold_keys[cur_buf].p;
+  uint32_t stalled = 0, rows_before = m->dir_used;
   for (uint32_t round = 0; cur_n; round++) {
     if (stalled > 8) smx_die("write batch did not converge (corrupt row table?)");
     const uint32_t dir_limit = m->dir_size / 2;
@@ -2292,6 +2329,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
   if (const char* a = getenv("SMATRIX_RETRY_SPLIT")) m->retry_split = *a != '0';
   if (const char* a = getenv("SMATRIX_SMALL_FIRST")) m->small_first = *a != '0';
+  if (const char* a = getenv("SMATRIX_RETRY_FAR")) m->retry_far = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_FAR")) m->cold_far = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_FAR_MAX")) m->cold_far_max = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters of k_grow_rest_lds from this batch on)

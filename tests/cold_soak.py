@@ -37,6 +37,8 @@ def run(configs=8, seed=1):
         kind = int(rng.integers(0, 3))
         base = int(rng.integers(1, 1 << 20)) if kind == 1 else 0
         gen = Stream("zipf", int(rng.integers(1, 1 << 30)), int(rng.choice([100000, 1000000])), 1.1, 0)
+        if os.environ.get("COLD_SOAK_TRACE") == str(c): os.environ["SMATRIX_TRACE_ROUNDS"] = "1"     # (the library reads it at open)
+        else: os.environ.pop("SMATRIX_TRACE_ROUNDS", None)
         g, o = GpuMatrix(), O.Oracle()
         at = 0
         for k in range(int(rng.integers(2, 4))):
@@ -48,6 +50,7 @@ def run(configs=8, seed=1):
                 h = rng.integers(0, 3, n) == 0
                 y = np.where(h, (y * np.uint32(2654435761)) | np.uint32(1), y).astype(np.uint32)
             op = 3 if (k == 1 and rng.integers(0, 2)) else 2
+            if os.environ.get("COLD_SOAK_TRACE") == str(c): print("config %d batch %d: %d rows, kind %d, base %d, n %d, op %d" % (c, k, nrows, kind, base, n, op), file=sys.stderr, flush=True)
             v = np.full(n, int(rng.integers(1, 4)), np.uint32)      # (one amount per batch: per-key return multisets are then order-free)
             a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
             kk = x.astype(np.uint64) << np.uint64(32) | y
