@@ -1635,7 +1635,11 @@ __global__ __launch_bounds__(256) void k_far_rows(Ctl* ctl, const DirSlot* dir, 
 // going to find out again: nothing changes in between) enter F.  `limit`: ops beyond it are not entered (the table would fill up).
 __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, const uint32_t* idx,
                                                   const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t st, uint4* tab,
-                                                  uint32_t tmask, uint32_t limit) {
+                                                  uint32_t tmask, uint32_t limit, uint32_t all_far) {
+  // all_far (the walkers of a cold round: keys known absent whose home cell is taken): every listed key of an indexed row enters F,
+  // however short its probe is now -- thousands of new keys of one hot row end their walks on the same few empty cells, and the
+  // ones that were not in F took them by compare-and-swap, one winner per cell and turn: 20 000 trips of 1.3 M clock ticks on
+  // average (the longest 10 M) in the six passes of the dense stream's first batch.  In F they claim their cell by rank.
   const uint32_t n = min(aload(&ctl->n_prev), limit);
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const size_t at = (size_t)idx[t] * st;
@@ -1646,7 +1650,7 @@ __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32
     const uint64_t* cells = row_cells(arena, s.z);
     uint32_t pos = Y & mask;
     bool far = true;
-    for (uint32_t step = 0; step <= HINT_BUDGET; step++) {
+    for (uint32_t step = 0; step <= HINT_BUDGET && !all_far; step++) {
       const uint64_t c = cells[pos];
       if (cell_key(c) == Y || c == 0) { far = false; break; }
       pos = (pos + 1) & mask;

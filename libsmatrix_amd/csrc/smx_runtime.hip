@@ -691,6 +691,7 @@ struct Matrix {
   DevBuf<unsigned long long> cold_set;
   DevBuf<uint32_t> cold_idx[2], cold_zero;   // the walks of a cold round through the far join: the list 0..n-1, what the pass leaves, zeroed amounts
   uint32_t cold_far_max = 1u << 20;     // ... in rounds of up to this many keys (SMATRIX_COLD_FAR_MAX): the early rounds' millions of keys sit in small rows, a lane walks them faster
+  bool cold_all_far = true;             // SMATRIX_COLD_ALL_FAR=0: only the walkers with a long probe enter the join's table (as in a steady batch)
   bool cold_far = true;                 // SMATRIX_COLD_FAR=0: the walks of a clustered table's cold rounds a wave per key (k_insert_keys)
   DevBuf<unsigned long long> cold_keys[3];   // the distinct pending keys, packed; what a round leaves deferred
 };
@@ -851,7 +852,7 @@ void clustered_sync(Matrix* m, hipStream_t s) {
 // The far join in front of the wave-per-op pass of a clustered write batch (smx_kernels.hpp "far join"): the table and the
 // occupancy bitmap are (re)built on stream s for the deferred list `dl` (length on the device: ctl->n_prev); every capacity is an
 // estimate -- what does not fit is left out of the table and takes the old walk.  Returns false when nothing was enqueued.
-bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32_t* x, const uint32_t* y, uint32_t est_nd) {
+bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32_t* x, const uint32_t* y, uint32_t est_nd, bool all_far = false) {
   if (!m->far_join || !m->home_on || m->dir_used == 0) return false;
   if (m->far_units_seen == 0) {
     // the first join of this matrix: how many rows and units there are is counted once, with a read-back
@@ -891,7 +892,7 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
                      m->far_tab.p, tmask);
   DBG_STEP(m, s, "k_far_rows");
   hipLaunchKernelGGL(k_far_keys, dim3(std::min<uint32_t>(blocks_for(est_nd), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, dl, x, y,
-                     m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u);
+                     m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u, all_far ? 1u : 0u);
   DBG_STEP(m, s, "k_far_keys");
   hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 32768)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_unit_row.p, cap_units,
                      m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p);
@@ -1398,7 +1399,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
         const uint32_t* xk = reinterpret_cast<const uint32_t*>(walk) + 1, * yk = reinterpret_cast<const uint32_t*>(walk);
         const uint32_t stride_was = m->in_stride;
         m->in_stride = 2;
-        far_joined = far_join_enqueue(m, s, m->cold_idx[0].p, xk, yk, cur_n);
+        far_joined = far_join_enqueue(m, s, m->cold_idx[0].p, xk, yk, cur_n, m->cold_all_far);
         if (far_joined) {
           hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), dim3(65536), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu,
                              m->cold_idx[0].p, xk, yk, m->cold_zero.p, m->cold_zero.p + 2 * (size_t)cur_n, m->cold_idx[1].p, 2u);     // (amounts: stride 2 like the keys, all zero; results: dense, behind them, nobody reads them)
@@ -2331,6 +2332,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_SMALL_FIRST")) m->small_first = *a != '0';
   if (const char* a = getenv("SMATRIX_RETRY_FAR")) m->retry_far = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_FAR")) m->cold_far = *a != '0';
+  if (const char* a = getenv("SMATRIX_COLD_ALL_FAR")) m->cold_all_far = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_FAR_MAX")) m->cold_far_max = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters of k_grow_rest_lds from this batch on)
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
