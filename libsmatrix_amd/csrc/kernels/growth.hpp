@@ -105,6 +105,7 @@ __device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* task
       k.count = 0;
       k.dup = 0;
       k.wrap_from = k.wrap_seen = 0xFFFFFFFFu;
+      k.n_disp = 0;
     }
     __syncthreads();
   }
@@ -137,12 +138,19 @@ __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, GrowTask*
       __syncthreads();
       const uint64_t* O = row_cells(arena, k.old_base);
       const uint32_t old_size = 1u << k.old_lg;
-      for (uint32_t b0 = 0; b0 < old_size; b0 += blockDim.x) {                 // block-uniform
-        const uint32_t p = b0 + threadIdx.x;
-        const uint64_t c = O[p];
-        if (c == 0) atomicMin(&l_end, p);
+      // (eight windows per turn: a dense row's first run is 10^5 cells -- 400 turns of two barriers were 0.2 ms of the round's critical path)
+      for (uint32_t b0 = 0; b0 < old_size; b0 += 8u * blockDim.x) {            // block-uniform (chunked rows: old_size is a multiple of 8 x 256)
+        uint64_t c[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) c[q] = O[b0 + q * blockDim.x + threadIdx.x];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) if (c[q] == 0) atomicMin(&l_end, b0 + q * blockDim.x + threadIdx.x);
         __syncthreads();
-        if (c != 0 && p < l_end && (cell_key(c) & (old_size - 1u)) > p) atomicMin(&l_wrap, cell_key(c) & (old_size - 1u));
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+          const uint32_t p = b0 + q * blockDim.x + threadIdx.x;
+          if (c[q] != 0 && p < l_end && (cell_key(c[q]) & (old_size - 1u)) > p) atomicMin(&l_wrap, cell_key(c[q]) & (old_size - 1u));
+        }
         const bool done = l_end != 0xFFFFFFFFu;                                   // (uniform: read between two barriers)
         __syncthreads();
         if (done) break;
@@ -336,8 +344,11 @@ __global__ __launch_bounds__(256) void k_grow_move(const Ctl* ctl, GrowTask* tas
 // without looking at them; k_grow_finish's duplicate check skips them the same way (an at-home resident's key is
 // congruent to its own slot, so beyond the first slot of a probe sequence it cannot be the key looked for).
 // Taken when a batch has shown long probe sequences (Matrix::clustered); scrambled ids keep the single pass.
+// disp (round 6, the time-sliced k_grow_rest_lds): per old chunk the mask of its DISPLACED cells -- non-empty, not stored here --
+// and their number per task (GrowTask::n_disp): the slices of a row are cut by these counts, and a slice enters the cells in
+// front of it without loading the at-home ones
 __device__ __forceinline__ void grow_move_home_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old,
-                                                    uint8_t* arena) {
+                                                    uint8_t* arena, unsigned long long* disp) {
   const uint32_t nchunks = aload(&ctl->n_chunks);
   const uint32_t wave = (g.bid * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, nwaves = (g.nb * blockDim.x) >> 6;
   for (uint32_t ch = wave; ch < nchunks; ch += nwaves) {
@@ -358,6 +369,10 @@ __device__ __forceinline__ void grow_move_home_body(VGrid g, const Ctl* ctl, Gro
     const bool hi = home && (key & old_size);                   // new home = p + old_size
     if (home) row_cells(arena, k.new_base)[hi ? p + old_size : p] = pack_cell(key, p + 1);     // {key, priority}, like a moving cell
     const uint64_t lo_m = __ballot(home && !hi), hi_m = __ballot(hi);
+    if (disp) {
+      const uint64_t dm = m & ~(lo_m | hi_m);
+      if (lane == 0) disp[ch] = dm;                  // (counted per row by k_grow_rest_count: one atomic per chunk on a row's one word made this pass 0.5 ms)
+    }
     if (lane == 0) {
       // the masks ARE the new table's at-home bitmap (HOME_LG): they stay behind the block for the op kernels' probes
       unsigned long long* hb = row_home(arena, k.new_base, k.old_lg + 1);
@@ -366,8 +381,9 @@ __device__ __forceinline__ void grow_move_home_body(VGrid g, const Ctl* ctl, Gro
     }
   }
 }
-__global__ __launch_bounds__(256) void k_grow_move_home(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena) {
-  grow_move_home_body(SMX_VG, ctl, tasks, map_old, arena);
+__global__ __launch_bounds__(256) void k_grow_move_home(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, uint8_t* arena,
+                                                        unsigned long long* disp) {
+  grow_move_home_body(SMX_VG, ctl, tasks, map_old, arena, disp);
 }
 
 // the first slot at/after i (cyclically) that no at-home cell holds (`bits`: the row's mask words), as a walk that keeps
@@ -389,6 +405,7 @@ struct HomeWalk {
 
 // (rows whose displaced cells k_grow_rest_lds places, below: the new table's bitmap fits in LDS and no cell is wrapped)
 constexpr uint32_t REST_LDS_MAX_LG = 20;                 // new table: 2^20 bits = 128 KB of LDS
+constexpr uint32_t REST_TAKEN = 0x80000000u;             // GrowTask::n_disp: k_grow_rest_plan dealt the row out to k_grow_rest_lds
 __device__ inline bool rest_by_lds(const GrowTask& k) {
   return k.old_lg + 1 <= REST_LDS_MAX_LG && k.wrap_seen >= k.wrap_from;      // (wrap_seen < wrap_from: redone serially at the commit)
 }
@@ -403,7 +420,7 @@ __device__ __forceinline__ void grow_move_rest_body(VGrid g, const Ctl* ctl, Gro
     const uint32_t old_size = 1u << k.old_lg, p = (ch - k.chunk0) * 64 + lane;
     uint64_t cur = row_cells(arena, k.old_base)[p];
     if (k.wrap_seen < k.wrap_from && lane == 0) tasks[t].dup = 1;             // (see GrowTask::wrap_seen: redone serially at the commit)
-    if (by_lds && rest_by_lds(k)) continue;                                      // (k_grow_rest_lds places this row's displaced cells)
+    if (by_lds && (k.n_disp & REST_TAKEN)) continue;                              // (k_grow_rest_lds has placed this row's displaced cells)
     if (cur == 0 || (cell_key(cur) != 0 && (cell_key(cur) & (old_size - 1u)) == p && p < k.wrap_from)) continue;           // empty, or placed by the first pass
     uint64_t* T = row_cells(arena, k.new_base);
     const unsigned long long* bits = row_home(arena, k.new_base, k.old_lg + 1);
@@ -476,7 +493,7 @@ constexpr uint32_t REST_THREADS = 512, REST_WAVES = REST_THREADS / 64;     // (8
 constexpr uint32_t REST_STAGE = 320;                     // staged cells per wave (a step takes 64; up to 4 x 64 arrive at once)
 constexpr uint32_t REST_BUCKETS = 256;                   // per wave: {slot, lowest lane that wants it}, open addressing
 __host__ __device__ inline size_t rest_lds_bytes() {
-  return ((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX_LG - 9)) + (size_t)REST_WAVES * REST_STAGE * 8 + (size_t)REST_WAVES * REST_BUCKETS * 4 + (REST_WAVES + 2) * 4;
+  return ((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX_LG - 9)) + (size_t)REST_WAVES * REST_STAGE * 8 + (size_t)REST_WAVES * REST_BUCKETS * 4 + (REST_WAVES + 4) * 4;
 }
 // the first clear bit at/after slot i (cyclically) of the nw-word bitmap B; S: one bit per word of B, set when the word is full
 __device__ inline uint32_t lds_first_zero(const unsigned long long* B, const unsigned long long* S, uint32_t nw, uint32_t i) {
@@ -512,12 +529,118 @@ __device__ inline uint32_t lds_nth_zero(const unsigned long long* B, uint32_t nw
   return 0xFFFFFFFFu;
 }
 
-static_assert(((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX_LG - 9)) + (size_t)REST_WAVES * REST_STAGE * 8 + (size_t)REST_WAVES * REST_BUCKETS * 4 + (REST_WAVES + 2) * 4 <= 160 * 1024,
+static_assert(((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX_LG - 9)) + (size_t)REST_WAVES * REST_STAGE * 8 + (size_t)REST_WAVES * REST_BUCKETS * 4 + (REST_WAVES + 4) * 4 <= 160 * 1024,
               "k_grow_rest_lds: the LDS of one CU");
-// dbg (measurement runs only, SMATRIX_REST_DBG): counters {steps, rounds, cells, most steps of one wave, trips, most trips of one
+
+// ---- time slices (round 6) -------------------------------------------------------------------------------------------------------
+// One wave placing a piece's cells 64 per step is a SERIAL path as long as the piece: a dense row's run has no empty old slot in
+// 10^5 cells, 25 000 displaced cells in it were 390 steps of one wave (1.55 ms per dense-id batch while 250 CUs stood idle), and
+// the cells of its largest cluster -- a third of them, tools/probe/rest_census.c -- depend on each other through every hole of
+// the run, so no cut in SPACE exists.  The cut in TIME does: the set of slots taken after any prefix of the re-insertion order
+// does not depend on the order within the prefix (linear probing: a cell ends in the first free slot from its home, whoever
+// came before), only WHO sits where does.  So a row's displaced cells are cut into K slices of old slot order; the workgroup
+// of slice j first enters the cells of slices 0..j-1 into its bitmap in ANY order -- all 512 lanes at once, claims by atomic OR,
+// nothing stored -- and then places its own cells in order on exactly the bitmap the sequential re-insertion would have found
+// (src/smatrix.c:392-404), storing only those.  K workgroups of a row run on K compute units without talking to each other.
+//   k_grow_move_home leaves, per old chunk, the mask of its displaced cells and their count per row (GrowTask::n_disp);
+//   k_grow_rest_plan (one workgroup) deals out slices: ceil(n_disp / REST_SLICE_CELLS) per row, at most REST_MAX_SLICES, the
+//     rows with the most slices first, and marks the rows it took (bit 31 of n_disp: k_grow_move_rest leaves those alone);
+//   k_grow_rest_lds: a workgroup per slice.  The slice's range of old chunks is cut by the displaced counts (cell-balanced).
+constexpr uint32_t REST_SLICE_CELLS = 512;               // displaced cells a slice places in order (8 steps of one wave when they are one piece)
+constexpr uint32_t REST_MAX_SLICES = 64;
+// GrowTask::n_disp: a wave per 64 old chunks adds up their masks' bits, one atomic per wave and row
+__global__ __launch_bounds__(256) void k_grow_rest_count(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, const unsigned long long* disp) {
+  const uint32_t nchunks = aload(&ctl->n_chunks);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t c0 = wave * 64u; c0 < nchunks; c0 += nwaves * 64u) {        // (wave-uniform)
+    const uint32_t ch = c0 + lane;
+    uint32_t t = 0xFFFFFFFFu, cnt = 0;
+    if (ch < nchunks) { t = map_old[ch]; if (tasks[t].new_base != 0) cnt = (uint32_t)__popcll(disp[ch]); else t = 0xFFFFFFFFu; }
+    uint64_t todo = __ballot(t != 0xFFFFFFFFu);
+    while (todo) {                                                          // (one turn per row among the 64 chunks: mostly one)
+      const uint32_t l = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+      const uint32_t tv = (uint32_t)__shfl((int)t, (int)l);
+      const bool mine = t == tv;
+      uint32_t sum = mine ? cnt : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+      if (lane == l && sum) atomicAdd(&tasks[tv].n_disp, sum);
+      todo &= ~__ballot(mine);
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void k_grow_rest_plan(const Ctl* ctl, GrowTask* tasks, const uint32_t* list, uint32_t* tab, uint32_t tab_cap,
+                                                         uint32_t slice_cells) {
+  __shared__ uint32_t l_hist[REST_MAX_SLICES + 1], l_base[REST_MAX_SLICES + 1], l_cnt[REST_MAX_SLICES + 1], l_fits;
+  const uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
+  if (threadIdx.x <= REST_MAX_SLICES) { l_hist[threadIdx.x] = 0; l_cnt[threadIdx.x] = 0; }
+  __syncthreads();
+  auto slices_of = [&](uint32_t li) -> uint32_t {
+    const GrowTask k = tasks[list[li]];
+    if (k.new_base == 0 || grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE || !rest_by_lds(k)) return 0u;
+    return min(max(((k.n_disp & ~REST_TAKEN) + slice_cells - 1u) / slice_cells, 1u), REST_MAX_SLICES);
+  };
+  for (uint32_t li = threadIdx.x; li < n; li += blockDim.x) {
+    const uint32_t K = slices_of(li);
+    if (K) atomicAdd(&l_hist[K], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t K = REST_MAX_SLICES; K >= 1; K--) { l_base[K] = acc; acc += l_hist[K] * K; }
+    l_fits = acc <= tab_cap;                               // (the host sizes the table for every chunk the plan can have accepted: a guard)
+    tab[0] = l_fits ? acc : 0u;
+  }
+  __syncthreads();
+  if (!l_fits) return;                                     // nothing is marked: k_grow_move_rest moves every row by priority probing
+  for (uint32_t li = threadIdx.x; li < n; li += blockDim.x) {
+    const uint32_t K = slices_of(li);
+    if (!K) continue;
+    const uint32_t t = list[li], at = l_base[K] + atomicAdd(&l_cnt[K], 1u) * K;
+    for (uint32_t j = 0; j < K; j++) { tab[1 + 2 * (at + j)] = t; tab[2 + 2 * (at + j)] = j | (K << 16); }
+    tasks[t].n_disp |= REST_TAKEN;
+  }
+}
+
+// `valid` lanes enter a cell with home slot `home` into the bitmap, in any order (the set that results is the one of every order):
+// a lane claims the first free slot from its home by atomic OR; the lanes of the wave that lose the SAME slot go on behind it
+// together, the r-th of them to the r-th free slot (one slot per lane and turn instead of one winner per turn).  Every slot a
+// lane steps over was seen taken or is claimed in this turn by a lane that takes it or finds it taken.  Wave-uniform.
+__device__ inline void rest_enter(unsigned long long* B, unsigned long long* S, uint32_t nw, uint32_t nmask, bool valid, uint32_t home) {
+  const uint32_t lane = threadIdx.x & 63u;
+  bool pending = valid;
+  uint32_t cur = home, r = 0;
+  while (__any(pending)) {                                                  // (wave-uniform)
+    uint32_t z = 0xFFFFFFFFu;
+    if (pending) {
+      z = lds_first_zero(B, S, nw, cur);
+      if (r && z <= nmask) z = lds_nth_zero(B, nw, z, r);
+      if (z > nmask) pending = false;                                       // (cannot happen: the table is at most half full)
+    }
+    if (pending) {
+      const unsigned long long bit = 1ull << (z & 63u);
+      const unsigned long long before = atomicOr(&B[z >> 6], bit);
+      if (!(before & bit)) {
+        if ((before | bit) == ~0ull) atomicOr(&S[z >> 12], 1ull << ((z >> 6) & 63u));
+        pending = false;
+      }
+    }
+    uint64_t todo = __ballot(pending);
+    while (todo) {                                                          // (wave-uniform: one turn per slot that was lost)
+      const uint32_t l = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+      const uint32_t zv = (uint32_t)__shfl((int)z, (int)l);
+      const uint64_t same = __ballot(pending && z == zv);
+      if (pending && z == zv) r = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+      todo &= ~same;
+    }
+    cur = (z + 1u) & nmask;
+  }
+}
+
+// dbg (measurement builds only, SMX_REST_DBG): counters {steps, rounds, cells, most steps of one wave, trips, most trips of one
 // wave}; bit 0 of dbg_mode: the staged cells are dropped instead of placed (what the loads alone cost: tables wrong afterwards)
-__global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list, uint8_t* arena,
-                                                                unsigned long long* dbg, uint32_t dbg_mode) {
+__global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* tab, const unsigned long long* disp,
+                                                                uint8_t* arena, unsigned long long* dbg, uint32_t dbg_mode) {
   extern __shared__ unsigned long long l_rest[];
   unsigned long long* B = l_rest;                                           // 2^(REST_LDS_MAX_LG - 6) words
   unsigned long long* S = B + (1u << (REST_LDS_MAX_LG - 6));                // 2^(REST_LDS_MAX_LG - 12) words
@@ -527,10 +650,11 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
   uint64_t* stage = stage_all + wave * REST_STAGE;                          // {key, old slot + 1} of this wave's pending displaced cells, in old slot order
   uint32_t* bucket = scratch_all + wave * REST_BUCKETS;
   uint32_t* bound = scratch_all + REST_WAVES * REST_BUCKETS;                // where each wave's range of old slots begins
-  const uint32_t n = aload(&ctl->n_kind[GROW_CHUNKED]);
-  for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {                 // block-uniform
-    const GrowTask k = tasks[list[li]];
-    if (k.new_base == 0 || grow_kind(k.old_lg) != GROW_CHUNKED || k.chunk0 == CHUNK_NONE || !rest_by_lds(k)) continue;
+  uint32_t* cut = bound + REST_WAVES + 2;                                   // the slice's first chunk and the one behind its last
+  const uint32_t n_slices = tab[0];
+  for (uint32_t si = blockIdx.x; si < n_slices; si += gridDim.x) {          // block-uniform
+    const uint32_t ti = tab[1 + 2 * si], s_j = tab[2 + 2 * si] & 0xFFFFu, s_k = tab[2 + 2 * si] >> 16;
+    const GrowTask k = tasks[ti];
     const long long d_t0 = dbg ? clock64() : 0;
     long long d_place = 0;
     const uint32_t old_size = 1u << k.old_lg, omask = old_size - 1u, new_size = 2u * old_size, nmask = new_size - 1u, nw = new_size >> 6;
@@ -546,24 +670,89 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
       S[sw] = m;
     }
     __syncthreads();
-    // this wave's range of old slots: from the first empty old slot at/after its nominal start to the one of the next wave
+    const long long d_b = dbg ? clock64() : 0;
+    // the slice: old chunks [c_lo, c_hi), cut where the row's running count of displaced cells passes j/K and (j+1)/K of them
+    // (every workgroup of the row works the same cuts out of the same masks)
+    const uint32_t nck = old_size >> 6;
+    const unsigned long long* dm = disp + k.chunk0;
+    uint32_t c_lo = 0, c_hi = nck;
+    if (s_k > 1) {
+      const uint32_t n_disp = k.n_disp & ~REST_TAKEN;
+      const uint32_t t_lo = (uint32_t)((uint64_t)s_j * n_disp / s_k), t_hi = (uint32_t)((uint64_t)(s_j + 1u) * n_disp / s_k);
+      const uint32_t per = (nck + REST_THREADS - 1u) / REST_THREADS;
+      const uint32_t b0 = min(threadIdx.x * per, nck), b1 = min(b0 + per, nck);
+      uint32_t mine = 0;
+      for (uint32_t c = b0; c < b1; c++) mine += (uint32_t)__popcll(dm[c]);
+      uint32_t incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= (uint32_t)d) incl += o; }
+      uint32_t* wsum = reinterpret_cast<uint32_t*>(stage_all);              // (the staging area is idle until the cells come)
+      if (lane == 63) wsum[wave] = incl;
+      if (threadIdx.x == 0) { cut[0] = 0; cut[1] = nck; }
+      __syncthreads();
+      uint32_t front = incl - mine;                                         // displaced cells in front of chunk b0
+      for (uint32_t w = 0; w < wave; w++) front += wsum[w];
+      // the cut for a count t > 0: behind the first chunk that brings the running count to t
+      for (int e = 0; e < 2; e++) {
+        const uint32_t t = e ? t_hi : t_lo;
+        if ((e && s_j + 1u == s_k) || t == 0 || !(t > front && t <= front + mine)) continue;
+        uint32_t cum = front;
+        for (uint32_t c = b0; c < b1; c++) { cum += (uint32_t)__popcll(dm[c]); if (cum >= t) { cut[e] = c + 1u; break; } }
+      }
+      __syncthreads();
+      c_lo = cut[0]; c_hi = cut[1];
+      __syncthreads();
+    }
+    const uint32_t s_lo = c_lo << 6, s_hi = c_hi << 6;
+    const long long d_u0 = dbg ? clock64() : 0;
+    // the cells in front of the slice enter the bitmap in any order: 64 chunk masks per wave and trip, their cells' slots laid
+    // out in the staging area (up to 8 per chunk and turn), the keys of up to 512 cells loaded together
+    if (c_lo) {
+      uint32_t* st32 = reinterpret_cast<uint32_t*>(stage);                  // 2 * REST_STAGE old slot indices
+      const uint32_t* keys = reinterpret_cast<const uint32_t*>(O);
+      for (uint32_t c0 = wave * 64u; c0 < c_lo; c0 += REST_WAVES * 64u) {   // (wave-uniform)
+        const uint32_t c = c0 + lane;
+        unsigned long long mk = c < c_lo ? dm[c] : 0ull;
+        while (__any(mk != 0)) {                                            // (wave-uniform)
+          const uint32_t cnt = min(8u, (uint32_t)__popcll(mk));
+          uint32_t incl = cnt;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= (uint32_t)d) incl += o; }
+          const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+          uint32_t at = incl - cnt;
+          for (uint32_t i = 0; i < cnt; i++) { st32[at++] = (c << 6) + (uint32_t)__ffsll(mk) - 1u; mk &= mk - 1ull; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          uint32_t key[8];
+#pragma unroll
+          for (uint32_t q = 0; q < 8; q++) key[q] = q * 64u + lane < tot ? keys[2u * st32[q * 64u + lane]] : 0u;
+#pragma unroll
+          for (uint32_t q = 0; q < 8; q++)
+            if (q * 64u < tot) rest_enter(B, S, nw, nmask, q * 64u + lane < tot, key[q] & nmask);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
+      __syncthreads();
+    }
+    const long long d_u1 = dbg ? clock64() : 0;
+    // this wave's range of the slice's old slots: from the first empty old slot at/after its nominal start to the one of the
+    // next wave (the slice itself begins wherever its count does: what lies in front of it is in the bitmap)
     {
-      uint32_t b = wave * (old_size / REST_WAVES);
+      uint32_t b = s_lo + ((wave * (c_hi - c_lo)) / REST_WAVES) * 64u;
       if (wave != 0) {
         for (bool found = false; !found;) {                                 // (wave-uniform; eight 64-cell windows in flight)
           uint64_t c[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) { const uint32_t p = b + (uint32_t)q * 64u + lane; c[q] = p < old_size ? O[p] : 1ull; }
+          for (int q = 0; q < 8; q++) { const uint32_t p = b + (uint32_t)q * 64u + lane; c[q] = p < s_hi ? O[p] : 1ull; }
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             const uint64_t m = __ballot(c[q] == 0);
             if (m && !found) { b += (uint32_t)q * 64u + (uint32_t)__ffsll((unsigned long long)m) - 1u; found = true; }
           }
-          if (!found) { b += 512; if (b >= old_size) { b = old_size; found = true; } }
+          if (!found) { b += 512; if (b >= s_hi) { b = s_hi; found = true; } }
         }
       }
       if (lane == 0) bound[wave] = b;
-      if (threadIdx.x == 0) { bound[REST_WAVES] = old_size; bound[REST_WAVES + 1] = 0; }
+      if (threadIdx.x == 0) { bound[REST_WAVES] = s_hi; bound[REST_WAVES + 1] = 0; }
     }
     __syncthreads();
     const uint32_t lo = bound[wave], hi = bound[wave + 1];
@@ -571,7 +760,8 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
     // A table whose first run continues its last one round the end (wrapped cells: GrowTask::wrap_from): the wrapped cells sit
     // in the FIRST piece and come first in old slot order, but land among the cells of the LAST piece -- so the wave that holds
     // the end of the table starts only when wave 0 is through (bound[REST_WAVES + 1]); all other pieces stay independent.
-    if (k.wrap_seen != 0xFFFFFFFFu && wave != 0 && hi == old_size && lo < hi)
+    // (Only a slice that holds both ends: a later slice has entered the wrapped cells with everything else in front of it.)
+    if (k.wrap_seen != 0xFFFFFFFFu && wave != 0 && hi == old_size && lo < hi && s_lo == 0)
       while (__hip_atomic_load(&bound[REST_WAVES + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
     uint32_t n_st = 0;                                                      // staged cells (wave-uniform)
     uint32_t d_steps = 0, d_rounds = 0, d_trips = 0;
@@ -707,6 +897,10 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
       atomicMax(&dbg[50], (unsigned long long)(d_t2 - d_t0)); atomicMax(&dbg[51], (unsigned long long)(d_t1 - d_t0));
       atomicMax(&dbg[52], (unsigned long long)(d_t2 - d_t1)); atomicMax(&dbg[53], (unsigned long long)d_place);
       atomicAdd(&dbg[54], (unsigned long long)(d_t2 - d_t1)); atomicAdd(&dbg[55], (unsigned long long)d_place); atomicAdd(&dbg[56], 1ull);
+      atomicMax(&dbg[57], (unsigned long long)(d_u1 - d_u0)); atomicAdd(&dbg[58], (unsigned long long)(d_u1 - d_u0));   // (the cells in front of the slice)
+      atomicMax(&dbg[59], (unsigned long long)(d_b - d_t0)); atomicAdd(&dbg[60], (unsigned long long)(d_b - d_t0));     // (the bitmap)
+      atomicMax(&dbg[61], (unsigned long long)(d_u0 - d_b)); atomicAdd(&dbg[62], (unsigned long long)(d_u0 - d_b));     // (the cuts)
+      atomicMax(&dbg[63], (unsigned long long)(d_t1 - d_u1)); atomicAdd(&dbg[49], (unsigned long long)(d_t1 - d_u1));   // (the waves' ranges)
       if (wave == 0) atomicMax(&dbg[64 + ((dbg_mode >> 8) & 31u)], ((unsigned long long)((d_t2 - d_t0) >> 10) << 40) | ((unsigned long long)((d_t1 - d_t0) >> 10) << 20) | (unsigned long long)k.old_lg);
     }
   }

@@ -140,6 +140,7 @@ struct GrowTask {
   uint32_t wrap_from;    // the smallest old home among the wrapped cells of the table's first run (k_grow_map); none: 2^32-1
   uint32_t wrap_seen;    // the same over ALL cells, as the first pass comes across them; smaller than wrap_from (a wrapped cell
                          // behind a hole, quirk Q1/Q3) sends the row to the serial redo
+  uint32_t n_disp;       // clustered rows: cells the first pass did not store (k_grow_move_home) -- what k_grow_rest_lds places, in slices
 };
 
 // How a row is doubled: tables whose old cells and new slots fit in LDS are rebuilt there by one wave

@@ -574,6 +574,9 @@ struct Matrix {
   FreeLists fl = {};                    // their pointers/capacities as passed to the kernels
   int32_t free_cnt[N_CLASSES] = {0};    // host mirror of the stack heights (last readback)
   DevBuf<uint32_t> map_old, map_new;
+  DevBuf<unsigned long long> disp_mask; // per old chunk of a growth round: its displaced cells (k_grow_move_home -> k_grow_rest_lds)
+  DevBuf<uint32_t> rest_tab;            // k_grow_rest_plan: {slices, then per slice: task, slice | slices of the row << 16}
+  uint32_t rest_slice_cells = REST_SLICE_CELLS, rest_grid = 768;     // (SMATRIX_REST_SLICE / SMATRIX_REST_GRID: measurements)
   DevBuf<uint64_t> cellp;
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
   DevBuf<uint64_t> soff;
@@ -1040,6 +1043,12 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   // chunk bounds: a table of 2^lg cells has max(1, 2^lg/64) chunks; units = 2^lg/16
   m->map_new.need((size_t)nt + gu / 4 + 1);
   m->map_old.need((size_t)nt + gu / 8 + 1);
+  if (m->clustered && m->home_on && m->rest_lds) {
+    // k_grow_rest_lds' time slices: a mask of displaced cells per old chunk, and the table of slices -- at most one per
+    // rest_slice_cells displaced cells of a row plus one per row, whatever the plan accepts of the chunks there is room for
+    m->disp_mask.need(m->map_old.cap);
+    m->rest_tab.need(2 + 2 * ((size_t)m->map_old.cap * 64 / m->rest_slice_cells + m->tasks.cap + 1));
+  }
   uint64_t cap_units = m->arena.mapped / UNIT_BYTES;
   if (spec && m->spec_tiny) cap_units = std::min<uint64_t>(cap_units, m->arena_next + gu);   // (tests: arena refusals too)
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, nt, s);     // every task retires one block
@@ -1084,12 +1093,16 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
                        two_pass ? m->arena.base : nullptr);
     if (two_pass) {
       hipLaunchKernelGGL(k_grow_move_home, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
-                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base);
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, m->rest_lds ? m->disp_mask.p : nullptr);
       // the displaced cells: a workgroup per row on an occupancy bitmap in LDS (k_grow_rest_lds); the chunked pass behind it
       // takes only what that kernel leaves (giant rows, rows with wrapped cells).  SMATRIX_REST_LDS=0: the chunked pass alone
-      if (m->rest_lds)
-        hipLaunchKernelGGL(k_grow_rest_lds, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 1024)), dim3(REST_THREADS), rest_lds_bytes(), sc,
-                           m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->arena.base, m->st.batches >= m->rest_dbg_from ? m->rest_dbg : nullptr, m->rest_dbg_mode | ((uint32_t)(m->st.batches & 31u) << 8));
+      if (m->rest_lds) {
+        hipLaunchKernelGGL(k_grow_rest_count, dim3(std::min<uint32_t>(blocks_for(oc_bound), 1024)), dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->disp_mask.p);
+        hipLaunchKernelGGL(k_grow_rest_plan, dim3(1), dim3(1024), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->rest_tab.p,
+                           (uint32_t)std::min<size_t>((m->rest_tab.cap - 2) / 2, 0x7FFFFFFFu), m->rest_slice_cells);
+        hipLaunchKernelGGL(k_grow_rest_lds, dim3(m->rest_grid), dim3(REST_THREADS), rest_lds_bytes(), sc,
+                           m->d_ctl, m->tasks.p, m->rest_tab.p, m->disp_mask.p, m->arena.base, m->st.batches >= m->rest_dbg_from ? m->rest_dbg : nullptr, m->rest_dbg_mode | ((uint32_t)(m->st.batches & 31u) << 8));
+      }
       hipLaunchKernelGGL(k_grow_move_rest, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                          dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, m->rest_lds);
     } else {
@@ -2325,6 +2338,8 @@ smatrix_t* smatrix_open(const char* fname) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
+  if (const char* a = getenv("SMATRIX_REST_SLICE")) m->rest_slice_cells = std::max<uint32_t>(64, (uint32_t)strtoul(a, nullptr, 10));
+  if (const char* a = getenv("SMATRIX_REST_GRID")) m->rest_grid = std::max<uint32_t>(1, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
   if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
@@ -2403,6 +2418,9 @@ void smatrix_close(smatrix_t* self) {
               c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
       fprintf(stderr, "[smatrix] k_grow_rest_lds clock ticks, longest of all launches: row %llu = set-up %llu + waves %llu (placing %llu); a wave on average: %.0f (placing %.0f) over %llu waves\n",
               c[50], c[51], c[52], c[53], c[54] / (double)std::max(1ull, c[56]), c[55] / (double)std::max(1ull, c[56]), c[56]);
+      fprintf(stderr, "[smatrix] k_grow_rest_lds phases, k ticks max / mean per wave: bitmap %llu / %.0f, cuts %llu / %.0f, cells in front %llu / %.0f, ranges %llu / %.0f, placing (wave) %llu / %.0f\n",
+              c[59] >> 10, c[60] / 1024.0 / std::max(1ull, c[56]), c[61] >> 10, c[62] / 1024.0 / std::max(1ull, c[56]), c[57] >> 10, c[58] / 1024.0 / std::max(1ull, c[56]),
+              c[63] >> 10, c[49] / 1024.0 / std::max(1ull, c[56]), c[52] >> 10, c[54] / 1024.0 / std::max(1ull, c[56]));
       for (int i = 0; i < 32; i++) if (c[64 + i]) fprintf(stderr, "[smatrix]   batch %%32 == %d: the row wave 0 of which ran longest: %llu k ticks, set-up %llu k, old table 2^%llu\n", i, c[64 + i] >> 40, (c[64 + i] >> 20) & 0xFFFFF, c[64 + i] & 0xFF);
       (void)hipFree(m->rest_dbg);
     }
@@ -2437,7 +2455,7 @@ void smatrix_close(smatrix_t* self) {
       m->cold_set.release(); m->cold_keys[0].release(); m->cold_keys[1].release(); m->cold_keys[2].release();
       m->cold_idx[0].release(); m->cold_idx[1].release(); m->cold_zero.release();
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_rank.release(); m->fx_excl.release(); m->fx_tiles.release();
-      m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->cellp.release();
+      m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->disp_mask.release(); m->rest_tab.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
       get_timing_resolve(m, 0);
       for (hipEvent_t e : m->ev_free) (void)hipEventDestroy(e);
