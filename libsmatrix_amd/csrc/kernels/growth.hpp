@@ -606,10 +606,10 @@ __global__ __launch_bounds__(1024) void k_grow_rest_plan(const Ctl* ctl, GrowTas
 // a lane claims the first free slot from its home by atomic OR; the lanes of the wave that lose the SAME slot go on behind it
 // together, the r-th of them to the r-th free slot (one slot per lane and turn instead of one winner per turn).  Every slot a
 // lane steps over was seen taken or is claimed in this turn by a lane that takes it or finds it taken.  Wave-uniform.
-__device__ inline void rest_enter(unsigned long long* B, unsigned long long* S, uint32_t nw, uint32_t nmask, bool valid, uint32_t home) {
+__device__ inline uint32_t rest_enter(unsigned long long* B, unsigned long long* S, uint32_t nw, uint32_t nmask, bool valid, uint32_t home) {
   const uint32_t lane = threadIdx.x & 63u;
   bool pending = valid;
-  uint32_t cur = home, r = 0;
+  uint32_t cur = home, r = 0, got = 0xFFFFFFFFu;                            // got: the slot the lane ended in
   while (__any(pending)) {                                                  // (wave-uniform)
     uint32_t z = 0xFFFFFFFFu;
     if (pending) {
@@ -623,6 +623,7 @@ __device__ inline void rest_enter(unsigned long long* B, unsigned long long* S, 
       if (!(before & bit)) {
         if ((before | bit) == ~0ull) atomicOr(&S[z >> 12], 1ull << ((z >> 6) & 63u));
         pending = false;
+        got = z;
       }
     }
     uint64_t todo = __ballot(pending);
@@ -635,6 +636,7 @@ __device__ inline void rest_enter(unsigned long long* B, unsigned long long* S, 
     }
     cur = (z + 1u) & nmask;
   }
+  return got;
 }
 
 // dbg (measurement builds only, SMX_REST_DBG): counters {steps, rounds, cells, most steps of one wave, trips, most trips of one
@@ -902,6 +904,123 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
       atomicMax(&dbg[61], (unsigned long long)(d_u0 - d_b)); atomicAdd(&dbg[62], (unsigned long long)(d_u0 - d_b));     // (the cuts)
       atomicMax(&dbg[63], (unsigned long long)(d_t1 - d_u1)); atomicAdd(&dbg[49], (unsigned long long)(d_t1 - d_u1));   // (the waves' ranges)
       if (wave == 0) atomicMax(&dbg[64 + ((dbg_mode >> 8) & 31u)], ((unsigned long long)((d_t2 - d_t0) >> 10) << 40) | ((unsigned long long)((d_t1 - d_t0) >> 10) << 20) | (unsigned long long)k.old_lg);
+    }
+  }
+}
+
+// ---- the far join: the absent keys of a row placed TOGETHER (round 6) ------------------------------------------------------------
+// A claimed insert (far_claim_insert) costs three atomics on words its row's other claimers want too -- the word's rank counter,
+// the live occupancy word, the ticket -- and every same-address atomic queues at the memory side: the 2 000 new keys that wrap
+// onto one hot row's run in a dense-id batch (10^4 in a young table's) went through their front's words one after the other,
+// and the pass in front of prep lasted as long as its hottest front, whatever the grid (0.65 ms per late batch, 1.7 ms per
+// young one).  The keys the join calls absent are known before that pass starts -- the entries of F without a slot -- and WHICH
+// free cell an absent key gets is the library's to choose as long as none between its home and its cell stays empty
+// (src/smatrix.c:343-380: some order of the reference's inserts).  So, between the scan and the pass:
+//   k_far_absent   one pass over F: every absent key takes a place in its row's bucket (one fetch-add on the row's count, kept at
+//                  the row's first unit; 32 entries per unit = cells / 16 per row), rows met for the first time enter a list;
+//   k_far_place    a workgroup per listed row: the row's occupancy words (as scanned) into LDS, tickets for all its keys at once
+//                  (sub_tickets_bulk / the row's `used`), the keys entered into the bitmap like the cells in front of a slice
+//                  (rest_enter: LDS atomics, ties broken by rank), {key, 0} stored with a compare-and-swap -- a cell the words
+//                  call free may hold the row's (0, v) entry -- and the slot written into the key's entry of F.
+// The pass then finds these keys like any far key that sits in its cell, and adds its amounts there.  What gets no ticket (the
+// row stands at its threshold) or no bucket entry stays absent and takes the old way (claim, deferral, prep).  Rows whose
+// bitmap does not fit in LDS (more than 2^REST_LDS_MAX_LG cells) too.
+constexpr uint32_t FAR_BUCKET_PER_UNIT = 32;
+// (two launches: rows of up to 2^FAR_PLACE_SMALL_LG cells a WAVE per row with 8 KB of LDS -- a thousand such rows per batch, and
+//  a workgroup that reserves the largest row's 130 KB keeps its compute unit to itself: 170 us --, the larger ones a workgroup of
+//  512 per row)
+constexpr uint32_t FAR_PLACE_SMALL_LG = 16;
+__host__ __device__ inline size_t far_place_lds_bytes(uint32_t max_lg) { return ((size_t)1 << (max_lg - 3)) + ((size_t)1 << (max_lg - 9)) + 64; }
+// rcnt[u]: absent keys of the row whose first unit is u (zeroed by k_far_scan); rcnt[cap_units]: rows in `rows`
+__global__ __launch_bounds__(256) void k_far_absent(const DirSlot* dir, const uint32_t* unit_row, uint8_t* arena, const uint4* tab, uint32_t tmask, uint32_t* rcnt,
+                                                    uint32_t cap_units, uint32_t* bucket, uint32_t* rows, uint32_t rows_cap) {
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  if (ah->twins || ah->far_overflow) return;                               // (uniform: the pass does not use the join then / takes no claimed inserts)
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e <= tmask; e += gridDim.x * blockDim.x) {
+    const uint4 v = tab[e];
+    if (v.x == 0 || v.z != FAR_NOT_FOUND) continue;                         // (unused, a row's own entry, or a key the scan has found)
+    const uint4* row = far_entry(const_cast<uint4*>(tab), tmask, v.y, 0u);
+    if (!row) continue;
+    const uint32_t fu = row->z;
+    const uint32_t at = atomicAdd(&rcnt[fu], 1u);
+    if (at == 0) { const uint32_t r = atomicAdd(&rcnt[cap_units], 1u); if (r < rows_cap) rows[r] = fu; }
+    // (the bucket: FAR_BUCKET_PER_UNIT entries per unit of the row, from the row's first unit on; what does not fit stays absent)
+    const uint32_t units = 1u << (meta_lg(dir[unit_row[fu]].meta) - FAR_UNIT_LG);
+    if (at < units * FAR_BUCKET_PER_UNIT) bucket[(size_t)fu * FAR_BUCKET_PER_UNIT + at] = e;
+  }
+}
+template <uint32_t FAR_PLACE_THREADS, uint32_t MIN_LG, uint32_t MAX_LG>
+__global__ __launch_bounds__(FAR_PLACE_THREADS) void k_far_place(DirSlot* dir, const uint32_t* unit_row, uint8_t* arena, uint4* tab, const uint32_t* rcnt,
+                                                                 uint32_t cap_units, const uint32_t* bucket, const uint32_t* rows, uint32_t rows_cap,
+                                                                 unsigned long long* occ, uint32_t* zeros, const unsigned long long* occ0) {
+  extern __shared__ unsigned long long l_place[];
+  unsigned long long* B = l_place;
+  unsigned long long* S = B + (1u << (MAX_LG - 6));
+  uint32_t* l_got = reinterpret_cast<uint32_t*>(S + (MAX_LG >= 12 ? 1u << (MAX_LG - 12) : 1u));
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  if (ah->twins || ah->far_overflow) return;
+  const uint32_t n_rows = min(rcnt[cap_units], rows_cap);
+  for (uint32_t ri = blockIdx.x; ri < n_rows; ri += gridDim.x) {            // block-uniform
+    const uint32_t fu = rows[ri], dslot = unit_row[fu];
+    const DirSlot d = dir[dslot];
+    const uint32_t lg = meta_lg(d.meta);
+    if (lg > MAX_LG || lg < MIN_LG) continue;                              // (block-uniform: another launch's rows, or none's)
+    const uint32_t mask = (1u << lg) - 1u, nw = 1u << (lg - 6), units = 1u << (lg - FAR_UNIT_LG);
+    const uint32_t n = min(rcnt[fu], units * FAR_BUCKET_PER_UNIT);         // (what the bucket holds)
+    uint64_t* cells = row_cells(arena, d.base);
+    __syncthreads();                                                        // (the previous row's bitmap is done with)
+    for (uint32_t w = threadIdx.x; w < nw; w += FAR_PLACE_THREADS) B[w] = occ0[(size_t)fu * FAR_UNIT_WORDS + w];
+    __syncthreads();
+    for (uint32_t sw = threadIdx.x; sw < (nw >> 6); sw += FAR_PLACE_THREADS) {
+      unsigned long long m = 0;
+      for (uint32_t b = 0; b < 64; b++) if (B[sw * 64 + b] == ~0ull) m |= 1ull << b;
+      S[sw] = m;
+    }
+    if (threadIdx.x < 64) {
+      // src/smatrix.c:346: a key goes in only while used <= size/2 -- tickets for as many of the row's keys as there is room for.
+      // A big row's 64 shares are looked at by the 64 lanes of the first wave together (nobody else touches the row in this
+      // launch; sub_tickets_bulk's walk from share to share was 45 us per big row): lane a takes from share a what the lanes
+      // below it leave wanted.
+      uint32_t got;
+      if (lg >= BIG_LG) {
+        SubCtr* sc = row_subs(arena, d.base, lg) + threadIdx.x;             // (SUBS == 64)
+        const uint32_t cnt = sc->cnt, quota = sc->quota, room = quota > cnt ? quota - cnt : 0u;
+        uint32_t incl = room;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, dd); if ((int)threadIdx.x >= dd) incl += o; }
+        const uint32_t before = incl - room, take = before >= n ? 0u : min(room, n - before);
+        if (take) sc->cnt = cnt + take;
+        got = min((uint32_t)__shfl((int)incl, 63), n);
+      } else {
+        const uint32_t cap = (mask + 1u) / 2u + 1u;
+        got = d.used < cap ? min(n, cap - d.used) : 0u;
+        if (got && threadIdx.x == 0) dir[dslot].used = d.used + got;
+      }
+      if (threadIdx.x == 0) {
+        if (got && !(d.meta & META_DIRTY)) dir[dslot].meta = d.meta | META_DIRTY;
+        *l_got = got;
+      }
+    }
+    __syncthreads();
+    const uint32_t got = *l_got;
+    for (uint32_t i0 = (threadIdx.x & ~63u); i0 < got; i0 += FAR_PLACE_THREADS) {     // (wave-uniform)
+      const uint32_t i = i0 + (threadIdx.x & 63u);
+      bool todo = i < got;
+      uint32_t e = 0, Y = 0, from = 0;
+      if (todo) { e = bucket[(size_t)fu * FAR_BUCKET_PER_UNIT + i]; Y = tab[e].x; from = Y & mask; }
+      while (__any(todo)) {                                                 // (wave-uniform)
+        const uint32_t z = rest_enter(B, S, nw, mask, todo, from);
+        if (todo) {
+          if (z > mask) { todo = false; continue; }                         // (cannot happen: the row holds at most size/2 + 1 keys)
+          const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[z]), 0ull, (unsigned long long)pack_cell(Y, 0u));
+          if (prev == 0) {
+            tab[e].z = z;
+            atomicOr(&occ[(size_t)fu * FAR_UNIT_WORDS + (z >> 6)], 1ull << (z & 63u));                  // (the live words: what the claimers and the probes read)
+            atomicSub(&zeros[fu + (z >> FAR_UNIT_LG)], 1u);
+            todo = false;
+          } else from = (z + 1u) & mask;                                    // (the row's (0, v) entry sits there: taken, on)
+        }
+      }
     }
   }
 }

@@ -283,18 +283,36 @@ __device__ inline uint32_t far_claim_insert(DirSlot* d, const uint4 s, uint8_t* 
                                             unsigned long long* occ, const uint32_t* zeros, uint64_t* cells, uint32_t mask, bool* deferred,
                                             uint32_t* where) {
   const uint32_t lg = meta_lg(s.x);
+  unsigned long long* cdbg = reinterpret_cast<const ArenaHead*>(arena)->dbg;     // (measurement runs: where a claimed insert spends its clock ticks; one key in 64)
+  if ((fmix32(Y) & 63u) != 0) cdbg = nullptr;
+  const long long c_t0 = cdbg ? clock64() : 0;
+  uint32_t c_words = 0, c_tries = 0;
   uint32_t* ticket = nullptr;                        // src/smatrix.c:346: insert only while used <= size/2 (as in apply_row)
   if (lg >= BIG_LG) {
     SubCtr* subs = row_subs(arena, s.z, lg);
     const uint32_t k0 = (blockIdx.x * 5u + threadIdx.x) & (SUBS - 1u);
     ticket = sub_ticket(subs + k0);
     if (!ticket) ticket = sub_ticket_elsewhere(subs, k0);
-    if (!ticket) { *deferred = true; return 0; }
+    if (!ticket) {
+      *deferred = true;
+      if (cdbg) { const long long c_t2 = clock64(); atomicAdd(&cdbg[113], 1ull); atomicAdd(&cdbg[114], (unsigned long long)(c_t2 - c_t0)); atomicMax(&cdbg[115], (unsigned long long)(c_t2 - c_t0)); }
+      return 0;
+    }
   } else {
     if (s.w > (mask + 1u) / 2u) { *deferred = true; return 0; }
     ticket = &d->used;
     if (atomicAdd(ticket, 1u) > (mask + 1u) / 2u) { atomicSub(ticket, 1u); *deferred = true; return 0; }
   }
+  const long long c_t1 = cdbg ? clock64() : 0;
+  const auto c_done = [&](uint32_t how) {
+    if (!cdbg) return;
+    const long long c_t2 = clock64();
+    atomicAdd(&cdbg[96], (unsigned long long)(c_t1 - c_t0)); atomicAdd(&cdbg[97], (unsigned long long)(c_t2 - c_t1)); atomicAdd(&cdbg[98], 1ull);
+    atomicMax(&cdbg[99], (unsigned long long)(c_t1 - c_t0)); atomicMax(&cdbg[100], (unsigned long long)(c_t2 - c_t1));
+    atomicAdd(&cdbg[101], (unsigned long long)c_words); atomicAdd(&cdbg[102], (unsigned long long)c_tries); atomicMax(&cdbg[103], (unsigned long long)c_words);
+    atomicAdd(&cdbg[104 + how], 1ull);
+    if (c_t2 - c_t0 > 100000) { atomicAdd(&cdbg[108], 1ull); atomicAdd(&cdbg[109], (unsigned long long)(c_t1 - c_t0)); atomicAdd(&cdbg[110], (unsigned long long)(c_t2 - c_t1)); atomicAdd(&cdbg[111], (unsigned long long)c_words); atomicAdd(&cdbg[112], (unsigned long long)c_tries); }
+  };
   const uint32_t first = OP == OP_DECR ? 0u - V : V;
   const uint32_t nwords = (mask + 1u) >> 6, wmask = nwords - 1u;
   // (round 5) Which free cell of a word a claimer gets is decided by RANK: one fetch-add on the word's counter, and the r-th
@@ -311,6 +329,7 @@ __device__ inline uint32_t far_claim_insert(DirSlot* d, const uint4 s, uint8_t* 
   uint32_t w = e0 >> 6;
   unsigned long long from = ~0ull << (e0 & 63u);     // (the first word counts from the front's bit only)
   for (uint32_t walked = 0; walked <= nwords + FAR_UNIT_WORDS;) {
+    c_words++;
     unsigned long long z = ~__hip_atomic_load(&occ[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & from;
     const unsigned long long z0 = ~occ0[w];
     const bool by_or = (z0 & ~from) != 0;
@@ -326,13 +345,18 @@ __device__ inline uint32_t far_claim_insert(DirSlot* d, const uint4 s, uint8_t* 
           if (rk >= nfree0) break;                    // every cell of this word that was free at the scan has its claimer
           b = select_bit(z0, rk);
         }
+        c_tries++;
         const unsigned long long bit = 1ull << b;
         const unsigned long long old = atomicOr(&occ[w], bit);
         z &= ~(old | bit);                            // (what the word really held: the bits others have set since are not tried)
         if (old & bit) continue;                      // somebody else's (a claimer by OR)
+        // (round 6) the unit's count of free cells is kept LIVE by the claims: the walk below steps over a unit whose cells
+        // have all been handed out since the scan as it steps over one that had none -- the 5 000th new key behind a hot
+        // front walked 100 used-up words, one round trip each (30 000 trips of 0.5 M clock ticks per dense-id batch)
+        atomicSub(const_cast<uint32_t*>(&zeros[w >> (FAR_UNIT_LG - 6)]), 1u);
         const uint32_t pos = (w << 6) + b;
         const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long*>(&cells[pos]), 0ull, (unsigned long long)pack_cell(Y, first));
-        if (prev == 0) { *where = pos; return first; }
+        if (prev == 0) { *where = pos; c_done(0); return first; }
         if (cell_key(prev) == Y) {                    // (not with one op per key; kept for safety: the cell is updated, the ticket goes back)
           atomicSub(ticket, 1u);
           uint32_t* vp = reinterpret_cast<uint32_t*>(&cells[pos]) + 1;
@@ -345,11 +369,12 @@ __device__ inline uint32_t far_claim_insert(DirSlot* d, const uint4 s, uint8_t* 
     from = ~0ull;
     w = (w + 1) & wmask;
     walked++;
-    if ((w & (FAR_UNIT_WORDS - 1u)) == 0)             // units without a free cell at the scan are full for good
-      while (walked <= nwords + FAR_UNIT_WORDS && zeros[w >> (FAR_UNIT_LG - 6)] == 0) { w = (w + FAR_UNIT_WORDS) & wmask; walked += FAR_UNIT_WORDS; }
+    if ((w & (FAR_UNIT_WORDS - 1u)) == 0)             // units without a free cell left (at the scan, or handed out since) are full for good
+      while (walked <= nwords + FAR_UNIT_WORDS && __hip_atomic_load(&zeros[w >> (FAR_UNIT_LG - 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) { w = (w + FAR_UNIT_WORDS) & wmask; walked += FAR_UNIT_WORDS; }
   }
   atomicSub(ticket, 1u);
   *deferred = true;
+  c_done(1);
   return 0;
 }
 
@@ -615,7 +640,14 @@ __device__ inline uint32_t apply_one(DirSlot* dir, uint32_t dmask, uint8_t* aren
 // FAR: the pass in front of prep of a clustered write batch, with the batch's far join at hand (ArenaHead::far_on)
 // SHORT: a lane per op that does NOT finish long probes: an op whose probe outruns the lane's budget (and the hint table) is
 //        deferred -- the first half of a clustered table's retry, see k_apply_short
-template <int OP, bool WPO = false, int HM = 0, bool FAR = false, bool SHORT = false>
+// WPK (round 6): ops per wave of a WPO kernel -- lanes 0, 64/WPK, ... hold one each.  What an op costs in such a pass is the
+// chain of dependent loads its lane makes alone (directory, the join's table, ticket, claim: ~20 000 clock ticks of 23 500 per
+// op, measured), the wave's cooperative probe is the smaller part: WPK lanes make their chains side by side and the wave takes
+// their probes one after the other.
+#ifndef SMX_WPO_OPS
+#define SMX_WPO_OPS 4
+#endif
+template <int OP, bool WPO = false, int HM = 0, bool FAR = false, bool SHORT = false, int WPK = 1>
 __device__ __forceinline__ void apply_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
@@ -626,7 +658,8 @@ __device__ __forceinline__ void apply_body(
   if (n == 0xFFFFFFFFu) n = aload(&ctl->n_prev);
   // (64-bit trip counter: with n > 2^31 ops and a grid that covers them all, t0 + the grid's size wraps around in 32 bits
   //  and the ops at the front would be applied a SECOND time -- round 3, found by the 2^31 + 2^27-op batch test)
-  const uint64_t n_lanes = WPO ? (uint64_t)n * 64u : (uint64_t)n;
+  constexpr uint32_t OP_LANES = WPO ? 64u / (uint32_t)WPK : 1u;          // lanes per op
+  const uint64_t n_lanes = (uint64_t)n * OP_LANES;
   const bool has_hints = HM == 1 || (HM == 2 && reinterpret_cast<const ArenaHead*>(arena)->hint_mask != 0);       // (wave-uniform)
   // (a wave per op with the join at hand: the lane looks at the home cell only -- nine dependent loads of the lane's own probe
   //  were half of such a pass's time; the wave's first window covers them in one load)
@@ -635,8 +668,8 @@ __device__ __forceinline__ void apply_body(
   const bool use_home = HM != 0 && reinterpret_cast<const ArenaHead*>(arena)->home_on != 0;                          // (wave-uniform)
   for (uint64_t t064 = (uint64_t)g.bid * blockDim.x; t064 < n_lanes; t064 += (uint64_t)g.nb * blockDim.x) {    // block-uniform
     const uint64_t tl = t064 + threadIdx.x;
-    const uint32_t t = WPO ? (uint32_t)(tl >> 6) : (uint32_t)tl;
-    const bool live = tl < n_lanes && (!WPO || (tl & 63u) == 0);
+    const uint32_t t = (uint32_t)(tl / OP_LANES);
+    const bool live = tl < n_lanes && (tl & (OP_LANES - 1u)) == 0;
     uint32_t j = 0, r = 0, Y = 0, V = 0;
     bool deferred = false;
     LongProbe lp{false, nullptr, 0, 0};
@@ -646,6 +679,7 @@ __device__ __forceinline__ void apply_body(
     unsigned long long* tdbg = WPO && FAR ? reinterpret_cast<const ArenaHead*>(arena)->dbg : nullptr;
     unsigned long long* hdbg = FAR && !WPO ? reinterpret_cast<const ArenaHead*>(arena)->dbg : nullptr;     // (a lane per op: how long a wave's trip takes, log2 buckets)
     const long long h0 = hdbg ? clock64() : 0;
+    const long long h0r = (WPO && !FAR && reinterpret_cast<const ArenaHead*>(arena)->dbg) ? clock64() : 0;
     long long h_find = 0, h_walk = 0, h_ins = 0;
     long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
     if (tdbg) tc0 = clock64();
@@ -780,6 +814,16 @@ __device__ __forceinline__ void apply_body(
         atomicAdd(&hdbg[20], (unsigned long long)mf); atomicAdd(&hdbg[21], (unsigned long long)mw); atomicAdd(&hdbg[22], (unsigned long long)mi);
         atomicAdd(&hdbg[23], (unsigned long long)tot); atomicAdd(&hdbg[24], 1ull);
         atomicMax(&hdbg[25], (unsigned long long)mw); atomicMax(&hdbg[26], (unsigned long long)mi); atomicMax(&hdbg[27], (unsigned long long)tot);
+      }
+    }
+    if (WPO && !FAR) {
+      // (measurement runs: the retry's wave-per-op pass -- ops, clock ticks, the trips above 10^5 ticks by row size 2^(4k..))
+      unsigned long long* rdbg = reinterpret_cast<const ArenaHead*>(arena)->dbg;
+      if (rdbg && live) {
+        const long long tt = clock64() - h0r;
+        atomicAdd(&rdbg[116], 1ull); atomicAdd(&rdbg[117], (unsigned long long)tt); atomicMax(&rdbg[118], (unsigned long long)tt);
+        if (tt > 100000) { atomicAdd(&rdbg[119], 1ull); atomicAdd(&rdbg[120], (unsigned long long)tt); atomicAdd(&rdbg[121 + min(meta_lg(s.x) / 4u, 5u)], 1ull); }
+        if (deferred) atomicAdd(&rdbg[127], 1ull);
       }
     }
     if (tdbg) {
@@ -1097,6 +1141,68 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
   }
 }
 
+// (round 6) GET on a clustered matrix.  With dense ids most ops end at their home cell -- two dependent loads -- and the rest
+// walked on cell by cell, asked the hint table, walked with their wave: up to twelve DEPENDENT loads, and every wave waited for
+// its few far lanes (0.90 ms per 2^24 gets against 0.40 on scrambled ids).  Here a lane that misses at home asks for the next
+// HINT_BUDGET cells AND its hint entry in one trip (the cells share a line or two; nothing depends on the order they arrive in),
+// looks through them in probe order, then at the hinted cell: four trips for a far key.  Same answers: the cells are examined
+// in the order of the reference's probe (src/smatrix.c:369-377, :299), a hint only names a cell that holds the key.
+// (Measured first: the unsettled ops compacted in LDS and run through the generic body by the first wave -- 1.2 ms: a quarter
+//  of the ops miss at home, and the second half made all their loads again.)
+__global__ __launch_bounds__(256) void k_get_clu(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n,
+                                                 const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t* __restrict__ out, uint32_t st) {
+  const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
+  const uint32_t hmask = ah->hint_mask;
+  const bool hints_ok = hmask != 0 && !ah->y0_zeroed;                      // (uniform; see hint_find)
+  const bool use_home = ah->home_on != 0;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * 256u; t0 < n; t0 += (uint64_t)gridDim.x * 256u) {      // block-uniform
+    const uint64_t t = t0 + threadIdx.x;
+    const bool live = t < n;
+    uint32_t r = 0, Y = 0;
+    LongProbe lp{false, nullptr, 0, 0};
+    if (live) {
+      const size_t at = (size_t)t * st;
+      Y = ys[at];
+      uint4 s;
+      DirSlot* d = dir_find(dir, dmask, xs[at], &s);
+      if (d && s.z != 0) {                                                   // (get on an absent row: 0, creates nothing, S1)
+        const uint32_t mask = (1u << meta_lg(s.x)) - 1u, home = Y & mask;
+        const uint64_t* cells = row_cells(arena, s.z);
+        const uint64_t c0 = cells[home];
+        if (cell_key(c0) == Y) r = cell_val(c0);
+        else if (c0 != 0) {
+          uint64_t c[HINT_BUDGET];
+#pragma unroll
+          for (uint32_t i = 0; i < HINT_BUDGET; i++) c[i] = cells[(home + 1u + i) & mask];
+          const bool ask = hints_ok && Y != 0;
+          uint4 e = {0, 0, 0, 0};
+          if (ask) e = ah->hints[hint_index(s.z, Y, hmask)];
+          bool settled = false;
+#pragma unroll
+          for (uint32_t i = 0; i < HINT_BUDGET; i++)
+            if (!settled && (cell_key(c[i]) == Y || c[i] == 0)) { settled = true; r = cell_key(c[i]) == Y ? cell_val(c[i]) : 0u; }
+          if (!settled && ask && e.x == Y && e.y == s.z && e.z <= mask) {
+            const uint64_t ch = cells[e.z];
+            if (cell_key(ch) == Y) { settled = true; r = cell_val(ch); }
+          }
+          if (!settled) lp = LongProbe{true, cells, mask, (home + 1u + HINT_BUDGET) & mask};
+        }
+      }
+    }
+    while (__any(lp.need)) {                                                // (wave-uniform: what is left walks with the wave)
+      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home, nullptr);
+      if (lp.need) {
+        lp.need = false;
+        if (p != PROBE_NONE) {
+          const uint64_t c = lp.cells[p];
+          if (cell_key(c) == Y) { r = cell_val(c); hint_put(arena, lp.cells, Y, p); }   // remembered for the next op that names it
+        }
+      }
+    }
+    if (live) out[t] = r;
+  }
+}
+
 // The pass in front of prep when the batch's far join is there: a LANE per op again.  With the join a far op is a table look-up
 // and, for a new key, a look at a few occupancy words -- no walk worth a whole wave (k_apply_wpo: 26 us per op and wave).
 template <int OP>
@@ -1121,7 +1227,7 @@ void k_apply_wpo_far(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
-  apply_body<OP, true, 2, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+  apply_body<OP, true, 2, true, false, SMX_WPO_OPS>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 // (round 5) The retry of a clustered table in two halves.  After the growth round most ops of the list are short again -- a key
@@ -1155,7 +1261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(SMX_APPLY_SGPRS
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
     const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
     const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
-  apply_body<OP, true, 2>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
+  apply_body<OP, true, 2, false, false, SMX_WPO_OPS>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
 }
 
 // ---- the scalar ABI's fast path: ONE op, arguments by value, result straight into pinned host memory
@@ -1667,13 +1773,17 @@ __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32
 // k_far_scan: a wave per unit: the occupancy words (a (0, v) cell counts as free: it may turn back into an empty one, quirk Q1),
 // the unit's count of free cells, and every displaced cell's slot into its key's entry of F, if it has one.
 __global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot* dir, const uint32_t* unit_row, uint32_t cap_units, uint8_t* arena,
-                                                  uint4* tab, uint32_t tmask, unsigned long long* occ, uint32_t* zeros, unsigned long long* occ0, uint32_t* clm) {
+                                                  uint4* tab, uint32_t tmask, unsigned long long* occ, uint32_t* zeros, unsigned long long* occ0, uint32_t* clm,
+                                                  uint32_t* rcnt) {
+  // rcnt (round 6, k_far_absent / k_far_place): per unit, the absent keys of the row that begins there -- zeroed here
   const uint32_t n_units = min(aload(&ctl->n_units), cap_units);
   const uint32_t lane = threadIdx.x & 63u, nwaves = (gridDim.x * blockDim.x) >> 6;
+  if (rcnt && blockIdx.x == 0 && threadIdx.x == 0) rcnt[cap_units] = 0;
   for (uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < n_units; u += nwaves) {     // (wave-uniform)
     const DirSlot d = dir[unit_row[u]];
     const uint32_t mask = (1u << meta_lg(d.meta)) - 1u;
     const uint4* row = far_entry(tab, tmask, d.base, 0u);                  // (a row that did not fit whole has no entry: its units are skipped)
+    if (rcnt && lane == 0) rcnt[u] = 0;
     if (!row) { if (lane == 0) zeros[u] = 0xFFFFFFFFu; continue; }
     const uint32_t p0 = (u - row->z) << FAR_UNIT_LG;
     const uint64_t* cells = row_cells(arena, d.base) + p0;

@@ -621,8 +621,11 @@ struct Matrix {
   // SMATRIX_FLUSH_MS (default 100; 0 = off), never more than ~1/10 of the time (the pause grows with the last flush)
   uint64_t flush_ms = 100;
   // flushes that release the matrix lock while they write (file_flush, snapshot mode): the FILE and its index belong to the
-  // holder of file_mu; lock order m->mu, then file_mu -- and nobody waits for m->mu while holding file_mu
+  // holder of file_mu.  Lock order (round 6): file_mu FIRST, then m->mu -- whoever wants to flush queues for the
+  // file without the matrix lock, so a write in flight (up to 2 GB under file_mu alone) never has a thread waiting for it
+  // with m->mu in its hand and every caller of the handle behind that thread.  Nobody takes file_mu while holding m->mu.
   std::mutex file_mu;
+  std::atomic<bool> ckpt_due{false};         // SMATRIX_FLUSH_EVERY: the call that is finishing owes a checkpoint (CkptAfter: taken once m->mu is released)
   uint64_t flush_snapshot = 2048ull << 20;   // bytes of row tables one such flush snapshots on the device (SMATRIX_FLUSH_SNAPSHOT_MB)
   hipStream_t flush_stream = nullptr;        // its copies to the host
   std::atomic<uint64_t> file_flushes_done{0}, file_rows_written_done{0}, file_bg_flushes_done{0};
@@ -673,6 +676,7 @@ struct Matrix {
   bool retry_split = true;              // SMATRIX_RETRY_SPLIT=0: the retry of a clustered table a wave per op in one launch
   bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0; uint64_t rest_dbg_from = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
+  bool get_split = true;                // SMATRIX_GET_SPLIT=0: gets of a clustered table a lane per op in one pass (k_apply<GET, hints>), as in round 5
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
   void* host_pipe = nullptr;            // HostPipe: the staging of large host-pointer batches (smatrix_apply_batch and friends)
   // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
@@ -683,6 +687,8 @@ struct Matrix {
   DevBuf<uint32_t> far_unit_row, far_zeros;
   DevBuf<unsigned long long> far_occ, far_occ0;
   DevBuf<uint32_t> far_clm;
+  DevBuf<uint32_t> far_rcnt, far_bucket, far_prows;   // k_far_absent / k_far_place: absent keys per row (at its first unit; + the row count), their entries of F, the rows that have any
+  bool far_place = true;                // SMATRIX_FAR_PLACE=0: the keys the join calls absent are inserted one by one by the pass (claims by rank), as in round 5
   uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
   uint32_t far_nd_seen = 0;             // ops in the list the last join was built for
   uint32_t far_rows_seen = 0, far_units_seen = 0;   // rows of >= 2^HOME_LG cells / their 1024-cell units when they were last counted
@@ -897,9 +903,21 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
   hipLaunchKernelGGL(k_far_keys, dim3(std::min<uint32_t>(blocks_for(est_nd), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, dl, x, y,
                      m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u, all_far ? 1u : 0u);
   DBG_STEP(m, s, "k_far_keys");
+  const bool place = m->far_place && !all_far;
+  if (place) { m->far_rcnt.need((size_t)cap_units + 1); m->far_bucket.need((size_t)cap_units * FAR_BUCKET_PER_UNIT); m->far_prows.need(cap_rows); }
   hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 32768)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_unit_row.p, cap_units,
-                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p);
+                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p, place ? m->far_rcnt.p : nullptr);
   DBG_STEP(m, s, "k_far_scan");
+  if (place) {
+    // the keys the scan has not found are placed a row at a time (k_far_place) before the pass looks for them
+    hipLaunchKernelGGL(k_far_absent, dim3(std::min<uint32_t>(blocks_for((uint64_t)1 << lg), 2048)), dim3(256), 0, s, m->d_dir, m->far_unit_row.p, m->arena.base, m->far_tab.p, tmask,
+                       m->far_rcnt.p, cap_units, m->far_bucket.p, m->far_prows.p, cap_rows);
+    hipLaunchKernelGGL((k_far_place<64, FAR_ROW_LG, FAR_PLACE_SMALL_LG>), dim3(2048), dim3(64), far_place_lds_bytes(FAR_PLACE_SMALL_LG), s, m->d_dir, m->far_unit_row.p, m->arena.base,
+                       m->far_tab.p, m->far_rcnt.p, cap_units, m->far_bucket.p, m->far_prows.p, cap_rows, m->far_occ.p, m->far_zeros.p, m->far_occ0.p);
+    hipLaunchKernelGGL((k_far_place<512, FAR_PLACE_SMALL_LG + 1, REST_LDS_MAX_LG>), dim3(256), dim3(512), far_place_lds_bytes(REST_LDS_MAX_LG), s, m->d_dir, m->far_unit_row.p, m->arena.base,
+                       m->far_tab.p, m->far_rcnt.p, cap_units, m->far_bucket.p, m->far_prows.p, cap_rows, m->far_occ.p, m->far_zeros.p, m->far_occ0.p);
+    DBG_STEP(m, s, "k_far_place");
+  }
   HIP_OK(hipGetLastError());
   arena_head_set(m, offsetof(ArenaHead, far_on), 1u, s);
   return true;
@@ -925,12 +943,14 @@ void launch_apply(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* idx, con
   }
   if (OP != OP_GET && idx && m->clustered && n <= m->wpo_max) {
     // a retry list of a clustered table: a wave per op (k_apply_wpo)
-    hipLaunchKernelGGL((k_apply_wpo<OP>), dim3(std::min<uint32_t>(blocks_for((uint64_t)n * 64), 65536)), dim3(256), 0, s, m->d_ctl, m->d_dir,
+    hipLaunchKernelGGL((k_apply_wpo<OP>), dim3(std::min<uint32_t>(blocks_for((uint64_t)n * (64 / SMX_WPO_OPS)), 65536)), dim3(256), 0, s, m->d_ctl, m->d_dir,
                        m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
     HIP_OK(hipGetLastError());
     return;
   }
-  if (m->d_hints)      // (the instantiation that asks the hint table after HINT_BUDGET cells: ArenaHead)
+  if (OP == OP_GET && m->d_hints && m->clustered && !idx && m->get_split)      // (clustered tables: a miss at home asks for the next cells and the hint together -- k_get_clu)
+    hipLaunchKernelGGL(k_get_clu, dim3(blocks_for(n)), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y, out, m->in_stride);
+  else if (m->d_hints)      // (the instantiation that asks the hint table after HINT_BUDGET cells: ArenaHead)
     hipLaunchKernelGGL((k_apply<OP, true>), dim3(blocks_for(n)), dim3(256), 0, s, m->d_ctl, m->d_dir,
                        m->dir_size - 1, m->arena.base, n, idx, x, y, v, out, defer, m->in_stride);
   else
@@ -1679,7 +1699,8 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         // the retry in two halves (k_apply_short): a lane per op for what is short again, then a wave per op over the rest; the
         // list that is left ends up in the buffer the retry READ, so the round's parity moves on by one (below)
         uint32_t* dl0 = dl;
-        const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * 64), 65536));
+        static const uint32_t wg2_env = getenv("SMATRIX_WPO_GRID2") ? (uint32_t)strtoul(getenv("SMATRIX_WPO_GRID2"), nullptr, 10) : 65536u;
+        const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * (64 / SMX_WPO_OPS)), wg2_env));
         switch (op) {
           case OP_SET:  hipLaunchKernelGGL((k_apply_short<OP_SET>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
           case OP_INCR: hipLaunchKernelGGL((k_apply_short<OP_INCR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
@@ -1902,17 +1923,29 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
   refresh_public(self);
   // SMATRIX_FLUSH_EVERY=N: the backing file is brought up to date after every N-th write batch (the reference's IO
   // thread writes dirty rows behind the caller's back all the time, src/smatrix.c:929-960; here it is a checkpoint)
-  if (op != OP_GET && m->flush_every && self->fd && m->st.batches % m->flush_every == 0) {
-    HIP_OK(hipStreamSynchronize(s));
-    // (the protocol of smatrix_flush -- ADVICE r3: a plain `dirty = false` here lost the flag of a lock-free scalar write
-    //  that had landed on another mirrored cell a moment before, and smatrix_close then skipped its final flush)
-    if (m->dirty.exchange(false)) {
-      if (!m->in_cache_sync) cache_sync(m, false);
-      std::lock_guard<std::mutex> fg(m->file_mu);
-      file_flush(self, m, false, nullptr);
-    }
-  }
+  // (round 6: the checkpoint itself is taken by the public entry point once it has let go of m->mu -- CkptAfter, checkpoint():
+  //  it needs file_mu, which is never waited for with the matrix lock held; a host-pointer call in chunks owes ONE)
+  if (op != OP_GET && m->flush_every && self->fd && !m->in_cache_sync && m->st.batches % m->flush_every == 0) m->ckpt_due = true;
 }
+
+// Brings the file up to date (SMATRIX_FLUSH_EVERY).  The protocol of smatrix_flush -- ADVICE r3: a plain `dirty = false` lost
+// the flag of a lock-free scalar write that had landed on another mirrored cell a moment before, and smatrix_close then
+// skipped its final flush.  Called WITHOUT m->mu.
+void checkpoint(smatrix_t* self) {
+  Matrix* m = M(self);
+  set_device(m);
+  std::unique_lock<std::mutex> fg(m->file_mu);
+  std::unique_lock<std::mutex> g(m->mu);
+  if (!self->fd || !m->dirty.exchange(false)) return;
+  cache_sync(m, false);
+  if (file_flush(self, m, false, &g)) m->dirty = true;
+}
+// Declared in a public entry point BEFORE it locks m->mu: runs after the lock is gone.
+struct CkptAfter {
+  smatrix_t* self;
+  explicit CkptAfter(smatrix_t* s) : self(s) {}
+  ~CkptAfter() { if (M(self)->ckpt_due.exchange(false)) checkpoint(self); }
+};
 
 // Writes the scalar ABI's mirrored values back (one batched set of cells that all exist: no structure change) before
 // anything reads the tables; `drop` additionally forgets the mirror (before writes that may touch mirrored cells).
@@ -1973,10 +2006,10 @@ void flusher_main(smatrix_t* self, Matrix* m) {
       bool more = false;
       {
         set_device(m);
+        std::lock_guard<std::mutex> fg(m->file_mu);       // (first: see Matrix::file_mu)
         std::unique_lock<std::mutex> g(m->mu);
         if (m->dirty.exchange(false)) {
           cache_sync(m, false);
-          std::lock_guard<std::mutex> fg(m->file_mu);
           // (round 4) the lock is held while the dirty rows are collected, laid out and snapshot on the device, and goes
           // back to the callers BEFORE the bytes are copied to the host and written (file_flush releases `g`)
           more = file_flush(self, m, false, &g);
@@ -2224,29 +2257,16 @@ int smatrix_flush(smatrix_t* self) {
   //  while they are written; the call itself returns when everything that was dirty at its start is in the file)
   // A BARRIER also against a flush that is in flight: the background flusher takes `dirty`, snapshots the rows,
   // drops the matrix lock and writes under file_mu alone -- a call that arrives during that write finds nothing dirty, yet the
-  // rows are not in the file and their CMAP entries not published.  So every turn first waits for file_mu WITHOUT the matrix
-  // lock (no caller is held up behind us meanwhile), and the call only returns after a turn in which it either ran a complete
-  // flush itself or found nothing dirty once the flush in flight had ended.
+  // rows are not in the file and their CMAP entries not published.  Every turn queues for file_mu FIRST and without the matrix
+  // lock (round 6: no caller of the handle is held up behind this call while somebody else's write goes on); once it has the
+  // file no flush is in flight, so "nothing dirty" then means everything is in the file.
   for (;;) {
-    { std::lock_guard<std::mutex> wait_for_flush_in_flight(m->file_mu); }
-    bool did = false, more = false;
-    {
-      std::unique_lock<std::mutex> g(m->mu);
-      if (m->dirty.exchange(false)) {
-        did = true;
-        cache_sync(m, false);
-        std::lock_guard<std::mutex> fg(m->file_mu);
-        more = file_flush(self, m, false, &g);
-        if (more) m->dirty = true;
-      }
-    }
-    if (did && !more) break;                     // everything dirty when this turn began has been written by it
-    if (!did) {
-      // nothing was dirty: either there was nothing to do, or a flush that started before this turn took the flag -- it holds
-      // file_mu until its rows are published (and raises `dirty` again if it left rows behind)
-      { std::lock_guard<std::mutex> wait_for_flush_in_flight(m->file_mu); }
-      if (!m->dirty.load()) break;
-    }
+    std::unique_lock<std::mutex> fg(m->file_mu);
+    std::unique_lock<std::mutex> g(m->mu);
+    if (!m->dirty.exchange(false)) break;
+    cache_sync(m, false);
+    if (!file_flush(self, m, false, &g)) break;    // everything dirty when this turn began has been written by it
+    m->dirty = true;                               // (the snapshot budget was reached: another turn)
   }
   return 0;
 }
@@ -2263,9 +2283,9 @@ int smatrix_compact(smatrix_t* self) {
   }
   if (m->fname.empty() || !self->fd) return 0;
   set_device(m);
+  std::lock_guard<std::mutex> fg(m->file_mu);
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, false);
-  std::lock_guard<std::mutex> fg(m->file_mu);
   file_compact(self, m);
   return 0;
 }
@@ -2338,6 +2358,10 @@ smatrix_t* smatrix_open(const char* fname) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
+  if (const char* a = getenv("SMATRIX_GET_SPLIT")) m->get_split = *a != '0';
+  if (const char* a = getenv("SMATRIX_FAR_PLACE")) m->far_place = *a != '0';
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_far_place<512, FAR_PLACE_SMALL_LG + 1, REST_LDS_MAX_LG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)far_place_lds_bytes(REST_LDS_MAX_LG)));
   if (const char* a = getenv("SMATRIX_REST_SLICE")) m->rest_slice_cells = std::max<uint32_t>(64, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_REST_GRID")) m->rest_grid = std::max<uint32_t>(1, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
@@ -2414,6 +2438,12 @@ void smatrix_close(smatrix_t* self) {
                          c[28], c[30] / (double)c[28], c[29], c[31], c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
       if (c[28] && !m->far_lanes) fprintf(stderr, "[smatrix]   ... their cycles: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f\n",
                                           c[40] / (double)c[28], c[41] / (double)c[28], c[42] / (double)c[28], c[43] / (double)c[28]);
+      if (c[98] || c[113]) fprintf(stderr, "[smatrix] claimed inserts: %llu (placed %llu, none left %llu), ticks per insert: ticket %.0f (max %llu), claim %.0f (max %llu); words %.1f (max %llu), tries %.2f | above 10^5 ticks: %llu, ticket %.0f, claim %.0f, words %.1f, tries %.1f | no ticket: %llu, %.0f ticks (max %llu)\n",
+              c[98], c[104], c[105], c[96] / (double)std::max(1ull, c[98]), c[99], c[97] / (double)std::max(1ull, c[98]), c[100], c[101] / (double)std::max(1ull, c[98]), c[103], c[102] / (double)std::max(1ull, c[98]),
+              c[108], c[109] / (double)std::max(1ull, c[108]), c[110] / (double)std::max(1ull, c[108]), c[111] / (double)std::max(1ull, c[108]), c[112] / (double)std::max(1ull, c[108]),
+              c[113], c[114] / (double)std::max(1ull, c[113]), c[115]);
+      if (c[116]) fprintf(stderr, "[smatrix] retry's wave-per-op pass: %llu ops, %.0f ticks on average (max %llu); above 10^5 ticks: %llu (%.0f on average) by row size 2^(4k..): %llu %llu %llu %llu %llu %llu; deferred %llu\n",
+                          c[116], c[117] / (double)c[116], c[118], c[119], c[120] / (double)std::max(1ull, c[119]), c[121], c[122], c[123], c[124], c[125], c[126], c[127]);
       fprintf(stderr, "[smatrix] k_grow_rest_lds: steps %llu rounds %llu | most steps of a wave %llu, most rounds %llu | trips %llu, most of a wave %llu | per round: losers %.2f blocked %.2f committed %.2f\n",
               c[0], c[1], c[3], c[6], c[4], c[5], c[8] / (double)std::max(1ull, c[1]), c[9] / (double)std::max(1ull, c[1]), c[10] / (double)std::max(1ull, c[1]));
       fprintf(stderr, "[smatrix] k_grow_rest_lds clock ticks, longest of all launches: row %llu = set-up %llu + waves %llu (placing %llu); a wave on average: %.0f (placing %.0f) over %llu waves\n",
@@ -2430,9 +2460,9 @@ void smatrix_close(smatrix_t* self) {
       m->flusher.join();
     }
     {
+      std::lock_guard<std::mutex> fg(m->file_mu);
       std::lock_guard<std::mutex> g(m->mu);
       cache_sync(m, true);
-      std::lock_guard<std::mutex> fg(m->file_mu);
       if (!m->fname.empty() && self->fd && m->compact_at_close) file_compact(self, m);
       else if (!m->fname.empty() && self->fd && m->dirty.exchange(false)) file_flush(self, m, false, nullptr);   // a matrix that was only read has nothing to persist
       (void)hipStreamSynchronize(m->stream);
@@ -2448,7 +2478,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
       delete static_cast<HostPipe*>(m->host_pipe);
-      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release();
+      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release(); m->far_rcnt.release(); m->far_bucket.release(); m->far_prows.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
@@ -2484,6 +2514,7 @@ int smatrix_apply_batch_dev(smatrix_t* self, int op, size_t n, const uint32_t* d
                             void* hip_stream) {
   Matrix* m = M(self);
   set_device(m);
+  CkptAfter ckpt(self);                                  // (a checkpoint that falls due is taken after m->mu is released)
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
@@ -2501,6 +2532,7 @@ int smatrix_apply_packed_dev(smatrix_t* self, int op, size_t n, const uint32_t* 
   if (op != OP_GET && width != 3) return -1;               // writes need a value
   Matrix* m = M(self);
   set_device(m);
+  CkptAfter ckpt(self);                                  // (a checkpoint that falls due is taken after m->mu is released)
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
@@ -2519,6 +2551,7 @@ int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, co
   if (n >= (1ull << 32)) smx_die("batch too large (n must be < 2^32)");     // before anything is staged or copied
   Matrix* m = M(self);
   set_device(m);
+  CkptAfter ckpt(self);                                  // (a checkpoint that falls due is taken after m->mu is released)
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = m->stream;
@@ -2526,10 +2559,16 @@ int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, co
     // a large call: chunks through pinned memory, upload / kernels / return overlapped (host_pipeline)
     const uint32_t* in[3] = {x, y, op != OP_GET ? v : nullptr};
     m->no_ret = out == nullptr;
+    const uint64_t batches0 = m->st.batches;
     host_pipeline(m, n, in, out, [&](size_t cnt, uint32_t* dx, uint32_t* dy, uint32_t* dv, uint32_t* dout) {
       apply_dev_locked(self, op, cnt, dx, dy, dv, dout, s);
     });
     m->no_ret = false;
+    if (op != OP_GET) {
+      //  the call is ONE batch to the caller's statistics and to SMATRIX_FLUSH_EVERY, however many chunks it ran in
+      m->st.batches = batches0 + 1;
+      m->ckpt_due = m->flush_every && self->fd && m->st.batches % m->flush_every == 0;
+    }
     return 0;
   }
   m->sx.need(n); m->sy.need(n); m->so.need(n);
@@ -2794,6 +2833,7 @@ static uint32_t scalar_op(smatrix_t* self, int op, uint32_t x, uint32_t y, uint3
     ql.unlock();
     {
       set_device(m);
+      CkptAfter ckpt(self);                                  // (a checkpoint that falls due is taken after m->mu is released)
       std::lock_guard<std::mutex> g(m->mu);
       // a cell may have been mirrored while this request waited for the lock (another thread's device op on it):
       // look again -- under the matrix lock mirrored-ness cannot change under us
@@ -2968,6 +3008,7 @@ int smatrix_cf_import_sessions_dev(smatrix_t* self, size_t n_sessions, const uin
   if (n_sessions > 0xffffffffull) return -1;
   Matrix* m = M(self);
   set_device(m);
+  CkptAfter ckpt(self);                                  // (a checkpoint that falls due is taken after m->mu is released)
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, true);
   hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = the legacy default stream
