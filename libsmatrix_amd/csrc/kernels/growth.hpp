@@ -21,8 +21,13 @@
 // estimates, and a task that does not fit is REFUSED -- new_base 0: every later pass skips it, the commit takes the
 // row's growth flag back, its ops stay deferred and the host-driven loop finishes them.
 constexpr uint32_t CHUNK_NONE = 0xFFFFFFFFu;
+// pend_ctl / pend_cap_keys / task_of (round 6, clustered matrices): every accepted task takes a bucket of old size / 2 keys in
+// the round's key buffer (one reservation per workgroup on pend_ctl[1]; what does not fit gets none) and leaves its number at
+// its directory slot's entry of task_of, where k_pend_group finds it
 __device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl,
-                                               uint32_t task_budget, uint32_t chunk_cap) {
+                                               uint32_t task_budget, uint32_t chunk_cap, uint32_t* pend_ctl = nullptr, uint32_t pend_cap_keys = 0,
+                                               uint32_t* task_of = nullptr) {
+  __shared__ uint32_t l_pend, l_pend0, l_pend_ok;
   __shared__ uint32_t l_want[N_CLASSES], l_got[N_CLASSES];
   __shared__ int32_t l_top[N_CLASSES];
   // the two bump counters (chunk ranges, arena units) are reserved ONCE PER WORKGROUP, look-then-compare-and-swap so that
@@ -34,7 +39,7 @@ __device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* task
   const uint32_t n = aload(&ctl->n_tasks);
   for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
     if (threadIdx.x < N_CLASSES) l_want[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { l_chunks = 0; l_units = 0; l_chunk_ok = 1; l_unit_ok = 1; }
+    if (threadIdx.x == 0) { l_chunks = 0; l_units = 0; l_chunk_ok = 1; l_unit_ok = 1; l_pend = 0; l_pend_ok = 0; }
     __syncthreads();
     const uint32_t t = t0 + threadIdx.x;
     const bool live = t < n;
@@ -106,14 +111,76 @@ __device__ __forceinline__ void grow_plan_body(VGrid g, Ctl* ctl, GrowTask* task
       k.dup = 0;
       k.wrap_from = k.wrap_seen = 0xFFFFFFFFu;
       k.n_disp = 0;
+      k.pend_off = k.pend_cap = k.n_pend = 0;
+    }
+    if (pend_ctl) {                                                         // (uniform)
+      uint32_t my_pend = 0;
+      const bool takes = live && tasks[t].new_base != 0;
+      const uint32_t want = takes ? max(8u, (1u << tasks[t].old_lg) / 2u) : 0u;
+      if (takes) my_pend = atomicAdd(&l_pend, want);
+      __syncthreads();
+      if (threadIdx.x == 0 && l_pend) {
+        l_pend0 = atomicAdd(&pend_ctl[1], l_pend);
+        l_pend_ok = (uint64_t)l_pend0 + l_pend <= pend_cap_keys;
+      }
+      __syncthreads();
+      if (takes && l_pend_ok) {
+        tasks[t].pend_off = l_pend0 + my_pend;
+        tasks[t].pend_cap = want;
+        task_of[tasks[t].dslot] = t;
+      }
     }
     __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, uint64_t arena_cap_units, FreeLists fl,
-                                                   uint32_t task_budget, uint32_t chunk_cap) {
-  grow_plan_body(SMX_VG, ctl, tasks, arena_cap_units, fl, task_budget, chunk_cap);
+                                                   uint32_t task_budget, uint32_t chunk_cap, uint32_t* pend_ctl, uint32_t pend_cap_keys, uint32_t* task_of) {
+  grow_plan_body(SMX_VG, ctl, tasks, arena_cap_units, fl, task_budget, chunk_cap, pend_ctl, pend_cap_keys, task_of);
+}
+
+// ---- growth takes the waiting keys in (round 6) ------------------------------------------------------------------------------------
+// An op whose key is absent from a row at its threshold waits for the row to double (src/smatrix.c:346-348) and then went in
+// through the retry: one compare-and-swap per key on the first empty cell of its probe.  On a clustered row the waiting keys of
+// one run all probe to the SAME cell, one wins, the others look at the next cell and race again: the k-th key of a front made k
+// round trips -- 22 000 ops of a late dense-id batch took 0.3 ms EACH, and the retry's wave-per-op pass (0.6 ms; 1.7 ms per
+// young batch) lasted as long as its longest front whatever its grid.  But the kernels that rebuild a row hold its whole new
+// table in LDS (k_grow_lds) or its occupancy (k_grow_rest_lds), where a key finds its cell without a trip to memory.  So:
+//   k_prep          leaves {directory slot, key} for every op it finds absent;
+//   k_grow_plan     gives every row that doubles a bucket of old size / 2 keys -- the new table has no room for more;
+//   k_pend_group    after the plan: each record finds its row's task (task_of), enters a hash set (one op per key) and the bucket;
+//   k_grow_lds      re-inserts the old cells, then the waiting keys, by the same priority probing (a waiting key's priority is
+//                   old size + its place in the bucket: behind every old cell -- the reference's resize, then its inserts);
+//   k_grow_rest_lds the workgroup of a row's LAST slice -- its bitmap is the whole new table -- enters them like the cells in
+//                   front of a slice (rest_enter) and stores {key, PEND_MARK}; k_grow_finish turns the mark into the value 0.
+// As many keys as the new table may take (used <= size/2 before each insert): the rest, and the keys of rows that are moved by
+// the global-memory passes, wait for the retry as before.  The retry then finds the keys in place and adds its amounts
+// ({key, 0} first, then the op's arithmetic: src/smatrix.c:354-356 then :230/:241/:252); keys that landed beyond the lane's
+// budget are in the hint table.  Off while a probe chain may have been cut (ArenaHead::twins: the duplicate check walks old cells).
+constexpr uint32_t PEND_MARK = 0xFFFFFFFFu;              // the "old slot" of a key that had none
+__global__ __launch_bounds__(256) void k_pend_group(const Ctl* ctl, GrowTask* tasks, const uint32_t* task_of, const uint2* rec, uint32_t rec_cap,
+                                                    const uint32_t* pend_ctl, unsigned long long* hash, uint32_t hmask, uint32_t* keys) {
+  const uint32_t n = min(pend_ctl[0], rec_cap), n_tasks = aload(&ctl->n_tasks);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint2 r = rec[i];
+    const uint32_t t = task_of[r.x];
+    if (t >= n_tasks) continue;
+    const GrowTask k = tasks[t];
+    if (k.dslot != r.x || k.new_base == 0 || k.pend_cap == 0) continue;    // (a stale entry, a refused task, no bucket)
+    const unsigned long long key = ((unsigned long long)r.x << 32) | r.y;  // (y != 0: never the empty entry)
+    uint32_t e = fmix32(r.x * 0x9E3779B1u ^ r.y * 0x85EBCA77u) & hmask;
+    bool mine = false;
+    for (uint32_t guard = 0; guard < 64; guard++) {
+      unsigned long long prev = hash[e];
+      if (prev == 0ull) prev = atomicCAS(&hash[e], 0ull, key);
+      if (prev == 0ull) { mine = true; break; }
+      if (prev == key) break;                                              // another op has named this key
+      e = (e + 1) & hmask;
+    }
+    if (!mine) continue;                                                    // (or the set is crowded here: the key waits for the retry)
+    const uint32_t at = atomicAdd(&tasks[t].n_pend, 1u);
+    if (at < k.pend_cap) keys[k.pend_off + at] = r.y;
+  }
 }
 
 // chunk -> task maps, filled one wave per CHUNKED task (prep lists them: a steady batch has ~50 of them among 60 000
@@ -189,7 +256,7 @@ struct WaveScope {                                   // the lanes of one wave; L
 //   l_old : 2^old_lg cells, l_tab : 2^(old_lg+1) slot indices, l_cd : {count, dup}, all private to the scope
 template <typename S>
 __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, uint64_t* l_old, uint32_t* l_tab,
-                                              uint32_t* l_cd) {
+                                              uint32_t* l_cd, const uint32_t* pend_keys = nullptr) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
   const uint32_t tid = S::tid();
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
@@ -218,6 +285,27 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
   }
   if (mine) atomicAdd(&l_cd[0], mine);
   S::sync();
+  // the keys that wait for this doubling (k_pend_group), behind the old cells: priority old_size + place in the bucket
+  const uint32_t* pend = nullptr;
+  if (pend_keys && !twins && task->pend_cap) {
+    const uint32_t n_old = l_cd[0], cap = new_size / 2u + 1u;
+    const uint32_t take = n_old < cap ? min(min(task->n_pend, task->pend_cap), cap - n_old) : 0u;
+    S::sync();                                       // (everybody has read the count)
+    if (take) {
+      pend = pend_keys + task->pend_off;
+      for (uint32_t i = tid; i < take; i += S::T) {
+        uint32_t cur = old_size + i, q = pend[i] & nmask;
+        for (;;) {
+          const uint32_t prev = atomicMin(&l_tab[q], cur);
+          if (prev == NONE) break;
+          if (prev > cur) cur = prev;
+          q = (q + 1) & nmask;
+        }
+      }
+      if (tid == 0) l_cd[0] = n_old + take;
+    }
+    S::sync();
+  }
   // a key that a probe from its home finds in ANOTHER slot first is a duplicate (grow_fixdup_one) -- possible only once a
   // probe chain has been cut (ArenaHead::twins)
   if (twins)
@@ -242,8 +330,9 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
     unsigned long long* hb = row_home(arena, task->new_base, old_lg + 1);
     for (uint32_t q = tid; q < new_size; q += S::T) {
       const uint32_t r = l_tab[q];
-      const uint64_t c = r == NONE ? 0ull : l_old[r];
+      const uint64_t c = r == NONE ? 0ull : r >= old_size ? pack_cell(pend[r - old_size], 0u) : l_old[r];
       T[q] = c;
+      if (r != NONE && r >= old_size && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);   // (beyond the lane's budget: remembered)
       if (bits) {
         const uint64_t hm = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & nmask) == q);
         if ((q & 63u) == 0) hb[q >> 6] = hm;
@@ -263,13 +352,13 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
 // one workgroup (THREADS = 64: one wave) per task of the given kind
 template <int THREADS, uint32_t MAX_LG>
 __global__ __launch_bounds__(THREADS) void k_grow_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
-                                                      uint32_t kind, uint8_t* arena) {
+                                                      uint32_t kind, uint8_t* arena, const uint32_t* pend_keys) {
   extern __shared__ uint64_t l_dyn[];                               // 2^MAX_LG cells ...
   uint32_t* l_tab = reinterpret_cast<uint32_t*>(l_dyn + (1u << MAX_LG));   // ... and 2^(MAX_LG+1) slot indices
   __shared__ uint32_t l_cd[2];
   const uint32_t n = ctl->n_kind[kind];
   for (uint32_t li = blockIdx.x; li < n; li += gridDim.x)                     // block-uniform
-    grow_lds_task<BlockScope<THREADS>>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd);
+    grow_lds_task<BlockScope<THREADS>>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd, pend_keys);
 }
 
 // one wave per 64 old slots
@@ -642,7 +731,7 @@ __device__ inline uint32_t rest_enter(unsigned long long* B, unsigned long long*
 // dbg (measurement builds only, SMX_REST_DBG): counters {steps, rounds, cells, most steps of one wave, trips, most trips of one
 // wave}; bit 0 of dbg_mode: the staged cells are dropped instead of placed (what the loads alone cost: tables wrong afterwards)
 __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* tab, const unsigned long long* disp,
-                                                                uint8_t* arena, unsigned long long* dbg, uint32_t dbg_mode) {
+                                                                uint8_t* arena, unsigned long long* dbg, uint32_t dbg_mode, const uint32_t* pend_keys) {
   extern __shared__ unsigned long long l_rest[];
   unsigned long long* B = l_rest;                                           // 2^(REST_LDS_MAX_LG - 6) words
   unsigned long long* S = B + (1u << (REST_LDS_MAX_LG - 6));                // 2^(REST_LDS_MAX_LG - 12) words
@@ -762,8 +851,11 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
     // A table whose first run continues its last one round the end (wrapped cells: GrowTask::wrap_from): the wrapped cells sit
     // in the FIRST piece and come first in old slot order, but land among the cells of the LAST piece -- so the wave that holds
     // the end of the table starts only when wave 0 is through (bound[REST_WAVES + 1]); all other pieces stay independent.
-    // (Only a slice that holds both ends: a later slice has entered the wrapped cells with everything else in front of it.)
-    if (k.wrap_seen != 0xFFFFFFFFu && wave != 0 && hi == old_size && lo < hi && s_lo == 0)
+    // (Time slices: a slice that begins inside the first piece places the wrapped cells it holds with its wave 0; what lies in
+    //  front of a slice is in its bitmap already.  The cells the wrapped ones can meet are those of old slots >= wrap_from --
+    //  the last run, which the first pass did not take for cells at home -- wherever the slice's cuts fall in it: a slice of
+    //  a 32768-cell row held the first piece AND the first 300 cells of the last run, and ended before the table did.)
+    if (k.wrap_seen != 0xFFFFFFFFu && wave != 0 && hi > k.wrap_from && lo < hi)
       while (__hip_atomic_load(&bound[REST_WAVES + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
     uint32_t n_st = 0;                                                      // staged cells (wave-uniform)
     uint32_t d_steps = 0, d_rounds = 0, d_trips = 0;
@@ -891,6 +983,34 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
     }
     if (n_st) place(n_st);
     if (wave == 0 && lane == 0) __hip_atomic_store(&bound[REST_WAVES + 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // the row's LAST slice: the bitmap now is the whole new table -- the keys that wait for this doubling go in (see k_pend_group)
+    if (pend_keys && s_j + 1u == s_k && k.pend_cap && !reinterpret_cast<const ArenaHead*>(arena)->twins) {      // (block-uniform)
+      __syncthreads();                                                      // (every wave has placed its cells)
+      if (wave == 0) {
+        // non-empty old cells: the first pass's count (a big row's sits in the new block's sub-counter lines)
+        uint32_t n_old = lane == 0 ? aload(&tasks[ti].count) : 0u;
+        if (k.old_lg + 1 >= BIG_LG) n_old += __hip_atomic_load(&row_subs(arena, k.new_base, k.old_lg + 1)[lane].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (SUBS == 64)
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) n_old += (uint32_t)__shfl_xor((int)n_old, dd);
+        const uint32_t cap = new_size / 2u + 1u;
+        if (lane == 0) cut[0] = n_old < cap ? min(min(aload(&tasks[ti].n_pend), k.pend_cap), cap - n_old) : 0u;
+      }
+      __syncthreads();
+      const uint32_t take = cut[0];
+      const uint32_t* pend = pend_keys + k.pend_off;
+      unsigned long long* hbn = row_home(arena, k.new_base, k.old_lg + 1);
+      for (uint32_t i0 = wave * 64u; i0 < take; i0 += REST_THREADS) {        // (wave-uniform)
+        const bool valid = i0 + lane < take;
+        const uint32_t key = valid ? pend[i0 + lane] : 0u;
+        const uint32_t z = rest_enter(B, S, nw, nmask, valid, key & nmask);
+        if (valid && z <= nmask) {
+          T[z] = pack_cell(key, PEND_MARK);
+          if (z == (key & nmask)) atomicOr(&hbn[z >> 6], 1ull << (z & 63u));        // (at home: its bit in the at-home bitmap)
+          else if (((z - key) & nmask) > HINT_BUDGET) hint_put(arena, T, key, z);
+        }
+      }
+      if (threadIdx.x == 0 && take) atomicAdd(&tasks[ti].count, take);
+    }
     if (dbg && lane == 0) {
       atomicAdd(&dbg[0], (unsigned long long)d_steps); atomicAdd(&dbg[1], (unsigned long long)d_rounds);
       atomicMax(&dbg[3], (unsigned long long)d_steps); atomicAdd(&dbg[4], (unsigned long long)d_trips); atomicMax(&dbg[5], (unsigned long long)d_trips);
@@ -1044,6 +1164,7 @@ __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTa
       uint64_t* T = row_cells(arena, k.new_base);
       uint64_t c = T[q];
       if (c != 0) {
+        if (cell_val(c) == PEND_MARK) { T[q] = pack_cell(cell_key(c), 0u); continue; }      // a key that waited for this doubling: {key, 0}
         uint64_t o = row_cells(arena, k.old_base)[cell_val(c) - 1];
         T[q] = pack_cell(cell_key(c), cell_val(o));
         if (!twins) continue;

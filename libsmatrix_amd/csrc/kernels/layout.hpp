@@ -141,6 +141,10 @@ struct GrowTask {
   uint32_t wrap_seen;    // the same over ALL cells, as the first pass comes across them; smaller than wrap_from (a wrapped cell
                          // behind a hole, quirk Q1/Q3) sends the row to the serial redo
   uint32_t n_disp;       // clustered rows: cells the first pass did not store (k_grow_move_home) -- what k_grow_rest_lds places, in slices
+  // (round 6) the NEW keys that wait for this doubling (k_prep's records, k_pend_group): growth puts them into the new table itself
+  uint32_t pend_off;     // the row's bucket in the round's key buffer,
+  uint32_t pend_cap;     //   its capacity (old size / 2: the new table has no room for more; 0: none) and
+  uint32_t n_pend;       //   the distinct keys that asked for a place (may exceed the capacity: the rest waits for the retry)
 };
 
 // How a row is doubled: tables whose old cells and new slots fit in LDS are rebuilt there by one wave

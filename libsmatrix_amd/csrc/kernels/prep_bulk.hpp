@@ -37,7 +37,9 @@ __device__ __forceinline__ void prep_body(
     VGrid g, Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl, uint32_t st, uint32_t create_only, uint32_t wpo_max) {
+    FreeLists fl, uint32_t st, uint32_t create_only, uint32_t wpo_max, uint2* pend_rec = nullptr, uint32_t pend_rec_cap = 0, uint32_t* pend_ctl = nullptr) {
+  // pend_rec (round 6, clustered matrices): every op whose key is ABSENT leaves {directory slot, key} there (pend_ctl[0] counts
+  //             them): the rows that double in this round take these keys in as they are rebuilt (k_pend_group, growth.hpp)
   // wpo_max (clustered matrices): a list of at most so many ops is taken a WAVE per op -- lane 0 holds the op, the wave finishes
   //             its long probe -- like k_apply_wpo: a few hundred deferred ops of big clustered rows, 64 to a wave, walked their
   //             10^4..10^5 cells one lane after the other (7-16 ms for 300-700 ops of the dense-id stream's late rounds)
@@ -220,6 +222,19 @@ __device__ __forceinline__ void prep_body(
         absent = p == PROBE_NONE || cell_key(lp.cells[p]) != Y;     // the table is quiescent here: the answer is final
       }
     }
+    if (pend_rec) {                                 // (uniform) one reservation per wave
+      const bool rec = absent && base != 0 && lg >= ROW_FIRST_LG;
+      const uint64_t rm = __ballot(rec);
+      if (rm) {
+        uint32_t at = 0;
+        if (__lane_id() == (uint32_t)__ffsll((unsigned long long)rm) - 1u) at = atomicAdd(&pend_ctl[0], (uint32_t)__popcll(rm));
+        at = (uint32_t)__shfl((int)at, __ffsll((unsigned long long)rm) - 1);
+        if (rec) {
+          const uint32_t i = at + (uint32_t)__popcll(rm & ((1ull << __lane_id()) - 1ull));
+          if (i < pend_rec_cap) pend_rec[i] = uint2{h, Y};
+        }
+      }
+    }
     // D. once per row with an absent key: grow it iff it stands at the reference's threshold
     //    (src/smatrix.c:346-348); a big row with room left only has its quotas re-partitioned
     //    "Once per row" is decided in two steps: a wave-level election (ballots), then the wave
@@ -292,8 +307,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     Ctl* ctl, DirSlot* dir, uint32_t dmask, uint32_t dir_limit, uint8_t* arena,
     uint64_t arena_cap_units, const uint32_t* defer, const uint32_t* __restrict__ xs,
     const uint32_t* __restrict__ ys, GrowTask* tasks, uint32_t* klist, uint32_t kcap, uint32_t* rebal,
-    FreeLists fl, uint32_t st, uint32_t create_only, uint32_t wpo_max) {
-  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st, create_only, wpo_max);
+    FreeLists fl, uint32_t st, uint32_t create_only, uint32_t wpo_max, uint2* pend_rec, uint32_t pend_rec_cap, uint32_t* pend_ctl) {
+  prep_body(SMX_VG, ctl, dir, dmask, dir_limit, arena, arena_cap_units, defer, xs, ys, tasks, klist, kcap, rebal, fl, st, create_only, wpo_max, pend_rec, pend_rec_cap, pend_ctl);
 }
 
 // ---- the bulk path: many deferred ops (bulk loads, the first batches of a matrix) ---------------------------

@@ -687,6 +687,14 @@ struct Matrix {
   DevBuf<uint32_t> far_unit_row, far_zeros;
   DevBuf<unsigned long long> far_occ, far_occ0;
   DevBuf<uint32_t> far_clm;
+  // (round 6) growth takes the waiting keys in (growth.hpp, k_pend_group): prep's records, the keys grouped by growing row, the
+  // directory slot -> task map, the set that keeps one op per key, {records, bucket bump pointer}
+  DevBuf<uint2> pend_rec;
+  DevBuf<uint32_t> pend_keys, task_of, pend_ctl;
+  DevBuf<unsigned long long> pend_hash;
+  bool pend_on = true;                  // SMATRIX_PEND=0: the keys that wait for a doubling go in through the retry, as in round 5
+  bool pend_armed = false;              // the prep that has just been enqueued left records (the growth round that follows groups them)
+  uint32_t pend_est = 0;                // ... about so many
   DevBuf<uint32_t> far_rcnt, far_bucket, far_prows;   // k_far_absent / k_far_place: absent keys per row (at its first unit; + the row count), their entries of F, the rows that have any
   bool far_place = true;                // SMATRIX_FAR_PLACE=0: the keys the join calls absent are inserted one by one by the pass (claims by rank), as in round 5
   uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
@@ -1074,10 +1082,28 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   for (uint32_t c = 0; c < N_CLASSES; c++) ensure_free_cap(m, c, nt, s);     // every task retires one block
   // (spec: the arena holds gu units beyond the host's mirror of the bump pointer -- row creation in prep may have taken
   //  some of the slack ensure_arena_free was asked for, hence the cap is what is mapped, checked per allocation)
+  // the keys that wait for these doublings (k_prep's records): buckets by the plan, grouped right behind it
+  const bool pend = m->pend_armed && m->clustered && m->home_on;
+  m->pend_armed = false;
+  uint32_t pend_hash_lg = 16;
+  if (pend) {
+    m->pend_keys.need(std::min<uint64_t>(8ull * nt + 4ull * gu + 1024, 0x7FFFFFFFull));
+    m->task_of.need(m->dir_size);
+    while (pend_hash_lg < 24 && (1ull << pend_hash_lg) < 2ull * m->pend_est) pend_hash_lg++;
+    m->pend_hash.need((size_t)1 << pend_hash_lg);
+  }
   hipLaunchKernelGGL(k_grow_plan, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
                      m->d_ctl, m->tasks.p, cap_units, m->fl, spec ? nt : 0xFFFFFFFFu,
-                     spec ? (uint32_t)std::min<uint64_t>(m->map_old.cap, m->map_new.cap / 2) : 0xFFFFFFFFu);
+                     spec ? (uint32_t)std::min<uint64_t>(m->map_old.cap, m->map_new.cap / 2) : 0xFFFFFFFFu,
+                     pend ? m->pend_ctl.p : nullptr, (uint32_t)m->pend_keys.cap, m->task_of.p);
   DBG_STEP(m, s, "k_grow_plan");
+  if (pend) {
+    HIP_OK(hipMemsetAsync(m->pend_hash.p, 0, (size_t)8 << pend_hash_lg, s));
+    hipLaunchKernelGGL(k_pend_group, dim3(std::min<uint32_t>(blocks_for(std::max<uint32_t>(m->pend_est, 1)), 2048)), dim3(256), 0, s, m->d_ctl, m->tasks.p, m->task_of.p,
+                       m->pend_rec.p, (uint32_t)m->pend_rec.cap, m->pend_ctl.p, m->pend_hash.p, (1u << pend_hash_lg) - 1u, m->pend_keys.p);
+    DBG_STEP(m, s, "k_pend_group");
+  }
+  const uint32_t* pend_keys = pend ? m->pend_keys.p : nullptr;
   const uint32_t n_chunked = nk[GROW_CHUNKED];
   // the chunked passes of the large rows touch other rows than the in-LDS rehashes: they run on a helper stream beside
   // them, from the plan on (non-blocking stream + events: the caller's stream may be the legacy default stream, which a
@@ -1087,13 +1113,13 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   if (fork) HIP_OK(hipEventRecord(m->ev_fork, s));
   if (nk[0])
     hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), 16u << GROW_LG0, s,
-                       m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base);
+                       m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base, pend_keys);
   if (nk[1])
     hipLaunchKernelGGL((k_grow_lds<256, GROW_LG1>), dim3(std::min<uint32_t>(nk[1], 4096)), dim3(256), 16u << GROW_LG1, s,
-                       m->d_ctl, m->tasks.p, m->klist.p + m->klist_cap, 1u, m->arena.base);
+                       m->d_ctl, m->tasks.p, m->klist.p + m->klist_cap, 1u, m->arena.base, pend_keys);
   if (nk[2])
     hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), 16u << GROW_LG2, s,
-                       m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base);
+                       m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base, pend_keys);
   DBG_STEP(m, s, "k_grow_lds x3");
   const uint64_t oc_bound = (uint64_t)n_chunked + gu / 8, nc_bound = (uint64_t)n_chunked + gu / 4;
   hipStream_t sc = s;
@@ -1121,7 +1147,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
         hipLaunchKernelGGL(k_grow_rest_plan, dim3(1), dim3(1024), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->rest_tab.p,
                            (uint32_t)std::min<size_t>((m->rest_tab.cap - 2) / 2, 0x7FFFFFFFu), m->rest_slice_cells);
         hipLaunchKernelGGL(k_grow_rest_lds, dim3(m->rest_grid), dim3(REST_THREADS), rest_lds_bytes(), sc,
-                           m->d_ctl, m->tasks.p, m->rest_tab.p, m->disp_mask.p, m->arena.base, m->st.batches >= m->rest_dbg_from ? m->rest_dbg : nullptr, m->rest_dbg_mode | ((uint32_t)(m->st.batches & 31u) << 8));
+                           m->d_ctl, m->tasks.p, m->rest_tab.p, m->disp_mask.p, m->arena.base, m->st.batches >= m->rest_dbg_from ? m->rest_dbg : nullptr, m->rest_dbg_mode | ((uint32_t)(m->st.batches & 31u) << 8), pend_keys);
       }
       hipLaunchKernelGGL(k_grow_move_rest, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                          dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, m->rest_lds);
@@ -1453,7 +1479,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
     hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(blocks_for(cur_n, PREP_THREADS), m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                        m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                        (uint64_t)(m->arena.mapped / UNIT_BYTES), (const uint32_t*)nullptr, reinterpret_cast<const uint32_t*>(kout) + 1,
-                       reinterpret_cast<const uint32_t*>(kout), m->tasks.p, m->klist.p, m->klist_cap, m->rebal.p, m->fl, 2u, 2u, 0u);
+                       reinterpret_cast<const uint32_t*>(kout), m->tasks.p, m->klist.p, m->klist_cap, m->rebal.p, m->fl, 2u, 2u, 0u, (uint2*)nullptr, 0u, (uint32_t*)nullptr);
     HIP_OK(hipGetLastError());
     ctl_read(m, s);
     m->st.rounds++;
@@ -1627,10 +1653,19 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     const auto launch_prep = [&](const uint32_t* list) {
       // (a short list of a clustered matrix is taken a wave per op: the grid covers 64 lanes per op then)
       const uint32_t pgrid = m->clustered && cur_n <= 8192u ? blocks_for((uint64_t)cur_n * 64, PREP_THREADS) : blocks_for(cur_n, PREP_THREADS);
+      // (clustered matrices: the ops found absent leave their keys for the growth round -- growth.hpp, k_pend_group)
+      const bool pend = m->clustered && m->home_on && m->pend_on && m->in_stride != 3;
+      if (pend) {
+        m->pend_rec.need(std::min<size_t>(n, (size_t)1 << 22));
+        m->pend_ctl.need(16);
+        HIP_OK(hipMemsetAsync(m->pend_ctl.p, 0, 16, s));
+        m->pend_est = (uint32_t)std::min<uint64_t>(chained ? std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16) : cur_n, m->pend_rec.cap);
+      }
+      m->pend_armed = pend;
       hipLaunchKernelGGL(k_prep, dim3(std::min<uint32_t>(pgrid, m->prep_blocks)), dim3(PREP_THREADS), 0, s,
                          m->d_ctl, m->d_dir, m->dir_size - 1, dir_limit, m->arena.base,
                          (uint64_t)(m->arena.mapped / UNIT_BYTES), list, x, y, m->tasks.p, m->klist.p, m->klist_cap,
-                         m->rebal.p, m->fl, m->in_stride, 0u, m->clustered ? 8192u : 0u);
+                         m->rebal.p, m->fl, m->in_stride, 0u, m->clustered ? 8192u : 0u, pend ? m->pend_rec.p : nullptr, (uint32_t)m->pend_rec.cap, m->pend_ctl.p);
     };
     // Clustered tables (dense ids): the folding kernel sets every op aside whose probe outruns its budget -- 770 000 of a
     // 2^24-op batch of the dense stream, nearly all of them HITS on keys that sit far from home -- and prep then walked
@@ -2360,6 +2395,7 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
   if (const char* a = getenv("SMATRIX_GET_SPLIT")) m->get_split = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_PLACE")) m->far_place = *a != '0';
+  if (const char* a = getenv("SMATRIX_PEND")) m->pend_on = *a != '0';
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_far_place<512, FAR_PLACE_SMALL_LG + 1, REST_LDS_MAX_LG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)far_place_lds_bytes(REST_LDS_MAX_LG)));
   if (const char* a = getenv("SMATRIX_REST_SLICE")) m->rest_slice_cells = std::max<uint32_t>(64, (uint32_t)strtoul(a, nullptr, 10));
@@ -2479,6 +2515,7 @@ void smatrix_close(smatrix_t* self) {
       m->row_ret.release();
       delete static_cast<HostPipe*>(m->host_pipe);
       m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release(); m->far_rcnt.release(); m->far_bucket.release(); m->far_prows.release();
+      m->pend_rec.release(); m->pend_keys.release(); m->task_of.release(); m->pend_ctl.release(); m->pend_hash.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
         if (m->fl.list[c]) (void)hipFree(m->fl.list[c]);
