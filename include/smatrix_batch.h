@@ -157,9 +157,18 @@ typedef struct {
   double   kernel_ms[4];
   uint64_t kernel_launches[4];
   uint64_t kernel_ops[4];
+  /* (round 6; new fields are APPENDED from here on -- see smatrix_stats_sz) what the write batches cost the calling thread:
+   * wall time inside the write path, of it blocked on the device (read-backs between rounds: kernels were running), of it
+   * inside device allocations / frees / address-range maps; call - wait - alloc is host work with the device idle or ahead.
+   * Totals since open, then the same for the most recent write batch. */
+  double   write_call_ms, write_wait_ms, write_alloc_ms;
+  double   last_write_call_ms, last_write_wait_ms, last_write_alloc_ms;
 } smatrix_stats_t;
 
 void smatrix_stats(smatrix_t* self, smatrix_stats_t* out);
+/* The same for callers that may have been compiled against an older (shorter) version of the struct: at most `size` bytes
+ * are written (pass sizeof(smatrix_stats_t) as the caller's header defines it).  Fields are only ever appended. */
+void smatrix_stats_sz(smatrix_t* self, smatrix_stats_t* out, size_t size);
 /* File mode: writes every row that changed since the last flush to the backing file NOW (dirty rows only -- in
  * place when the row's table still has its on-disk size, else as a fresh block whose CMAP entry is re-pointed, the
  * reference's own scheme, src/smatrix.c:418-496); row blocks first, then the entries that publish them.  smatrix_close

@@ -18,7 +18,8 @@ class Stats(C.Structure):
         "deferred_ops", "rows_grown", "dir_grown", "rows_rebalanced", "long_probe_rounds", "scalar_cache_hits", "scalar_cache_flushes",
         "scalar_cache_flushed_cells", "bulk_rounds", "bulk_ops", "file_flushes", "file_rows_written", "file_leaked_bytes",
         "file_compactions", "spec_chains", "spec_refused", "file_bg_flushes", "cold_starts", "cold_keys", "clustered_mode", "set_located_by_fold", "flush_snapshots_refused")] + [
-        ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)]
+        ("kernel_ms", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_ops", C.c_uint64 * 4)] + [
+        (n, C.c_double) for n in ("write_call_ms", "write_wait_ms", "write_alloc_ms", "last_write_call_ms", "last_write_wait_ms", "last_write_alloc_ms")]
 
 
 class Handle(C.Structure):
@@ -73,6 +74,7 @@ def load():
         "smatrix_cf_import_sessions": (C.c_int, [H, C.c_size_t, u64p, u32p]),
         "smatrix_cf_import_sessions_dev": (C.c_int, [H, C.c_size_t, V, V, V, C.c_uint64, V]),
         "smatrix_stats": (None, [H, C.POINTER(Stats)]),
+        "smatrix_stats_sz": (None, [H, C.POINTER(Stats), C.c_size_t]),
         "smatrix_profile": (None, [H, C.c_int]),
         "smatrix_flush": (C.c_int, [H]),
         "smatrix_compact": (C.c_int, [H]),

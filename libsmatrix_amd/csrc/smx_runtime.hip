@@ -692,6 +692,7 @@ struct Matrix {
   DevBuf<uint2> pend_rec;
   DevBuf<uint32_t> pend_keys, task_of, pend_ctl;
   DevBuf<unsigned long long> pend_hash;
+  double w_call_s = 0, w_wait_s = 0, w_alloc_s = 0;      // write batches: wall time inside run_write, of it waiting for the device, of it in device allocations / frees
   bool pend_on = true;                  // SMATRIX_PEND=0: the keys that wait for a doubling go in through the retry, as in round 5
   bool pend_armed = false;              // the prep that has just been enqueued left records (the growth round that follows groups them)
   uint32_t pend_est = 0;                // ... about so many
@@ -742,9 +743,16 @@ void ctl_push_persistent(Matrix* m, hipStream_t s) {
   HIP_OK(hipStreamSynchronize(s));
 }
 
+// the host waits for the device inside a write batch (a read-back): counted, so that a caller can tell the time its batch spent
+// with kernels running from the time the host took between them (smatrix_stats_t::write_wait_ms)
+void sync_counted(Matrix* m, hipStream_t s) {
+  const double t0 = mono_s();
+  HIP_OK(hipStreamSynchronize(s));
+  m->w_wait_s += mono_s() - t0;
+}
 void ctl_read(Matrix* m, hipStream_t s) {
   HIP_OK(hipMemcpyAsync(m->h_ctl, m->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  sync_counted(m, s);
   m->dir_used = m->h_ctl->dir_used;
   m->arena_next = m->h_ctl->arena_next;
   memcpy(m->free_cnt, m->h_ctl->free_cnt, sizeof m->free_cnt);
@@ -1172,7 +1180,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   if (m->trace_rounds && nt > 1000 && !spec) {      // who grows?  (cells moved, by log2 of the old row size)
     std::vector<GrowTask> ht(nt);
     HIP_OK(hipMemcpyAsync(ht.data(), m->tasks.p, (size_t)nt * sizeof(GrowTask), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    sync_counted(m, s);
     uint64_t cnt[32] = {0};
     for (const GrowTask& k : ht) cnt[k.old_lg & 31]++;
     fprintf(stderr, "[smatrix]   growth by old size:");
@@ -1207,7 +1215,7 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
                        x, m->in_stride, m->cold_set.p, slots - 1, m->d_small + 12);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 8, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    sync_counted(m, s);
     const uint64_t need = (uint64_t)m->dir_used + m->h_small[12] + m->h_small[13];
     // the size the old one-factor-at-a-time growth would have ended at: x4 while the rows do not fit half the slots, x2
     // when they fill half of them afterwards
@@ -1291,7 +1299,7 @@ uint32_t run_bulk_t(Matrix* m, uint32_t nd, const uint32_t* dl, uint32_t* dl_out
   HIP_OK(hipGetLastError());
   uint64_t tw[2] = {0, 0};
   HIP_OK(hipMemcpyAsync(tw, m->fx_tiles.p + ntiles, 16, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  sync_counted(m, s);
   const uint64_t units = tw[0] >> 32;
   // 3. the new blocks: ONE reservation for all rows (their offsets are the scan's upper halves)
   ensure_arena_free(m, units, s);
@@ -1376,7 +1384,7 @@ bool insert_pending_keys(Matrix* m, const uint32_t* list, uint32_t n_list, const
                      n_list, list, x, y, m->in_stride, m->cold_set.p, slots - 1, m->cold_keys[0].p, m->d_small + 12);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(m->h_small + 12, m->d_small + 12, 8, hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  sync_counted(m, s);
   uint32_t cur_n = m->h_small[12];
   // dense ids: a quarter of the distinct keys below the length of the list (scrambled ids: one in 2^32 / n_list)
   const bool dense_keys = (uint64_t)m->h_small[13] * 4 >= cur_n;
@@ -1687,7 +1695,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       if (!chained && m->far_join && m->home_on) {
         uint32_t nd_now = 0;
         HIP_OK(hipMemcpyAsync(&nd_now, &m->d_ctl->n_prev, 4, hipMemcpyDeviceToHost, s));      // (k_round_advance has just moved it there)
-        HIP_OK(hipStreamSynchronize(s));
+        sync_counted(m, s);
         est_far = (uint64_t)nd_now + nd_now / 8 + 1024;
         if (m->trace_rounds) fprintf(stderr, "[smatrix] batch %llu: the folding kernel deferred %u ops\n", (unsigned long long)m->st.batches, nd_now);
       }
@@ -1904,7 +1912,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     hipLaunchKernelGGL(k_set_pick_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_store_e, g, b, 0, s, ne, m->ent_idx.p, m->cellp.p, v, m->arena.base, m->in_stride);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(s));
+    sync_counted(m, s);
   } else if (op == OP_SET) {
     dim3 g(blocks_for(n)), b(256);
     hipLaunchKernelGGL(k_set_locate, g, b, 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, y,
@@ -1914,7 +1922,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
     hipLaunchKernelGGL(k_set_pick, g, b, 0, s, n, m->cellp.p, m->arena.base);
     hipLaunchKernelGGL(k_set_store, g, b, 0, s, n, m->cellp.p, v, m->arena.base, m->in_stride);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(s));
+    sync_counted(m, s);
   }
 }
 
@@ -1954,7 +1962,17 @@ void apply_dev_locked(smatrix_t* self, int op, size_t n, const uint32_t* x, cons
   Matrix* m = M(self);
   if (n >= (1ull << 32)) smx_die("batch too large (n must be < 2^32)");
   if (op == OP_GET) run_get(m, (uint32_t)n, x, y, out, s);
-  else run_write(m, op, (uint32_t)n, x, y, v, out, s);
+  else {
+    // (what the call costs the host: smatrix_stats_t::write_call_ms / write_wait_ms / write_alloc_ms)
+    const double t0 = mono_s(), w0 = m->w_wait_s;
+    const AllocClock a0 = alloc_clock();
+    run_write(m, op, (uint32_t)n, x, y, v, out, s);
+    const AllocClock a1 = alloc_clock();
+    const double call = mono_s() - t0, wait = m->w_wait_s - w0, al = std::max(0.0, (a1.s_alloc + a1.s_free) - (a0.s_alloc + a0.s_free));
+    m->w_call_s += call; m->w_alloc_s += al;
+    m->st.write_call_ms = m->w_call_s * 1e3; m->st.write_wait_ms = m->w_wait_s * 1e3; m->st.write_alloc_ms = m->w_alloc_s * 1e3;
+    m->st.last_write_call_ms = call * 1e3; m->st.last_write_wait_ms = wait * 1e3; m->st.last_write_alloc_ms = al * 1e3;
+  }
   refresh_public(self);
   // SMATRIX_FLUSH_EVERY=N: the backing file is brought up to date after every N-th write batch (the reference's IO
   // thread writes dirty rows behind the caller's back all the time, src/smatrix.c:929-960; here it is a checkpoint)
@@ -3135,6 +3153,12 @@ void smatrix_stats(smatrix_t* self, smatrix_stats_t* out) {
   m->st.file_bg_flushes = m->file_bg_flushes_done.load();
   m->st.clustered_mode = m->clustered ? 1 : 0;
   *out = m->st;
+}
+//  the same for a caller compiled against an older, shorter header: only `size` bytes are written
+void smatrix_stats_sz(smatrix_t* self, smatrix_stats_t* out, size_t size) {
+  smatrix_stats_t full;
+  smatrix_stats(self, &full);
+  memcpy(out, &full, std::min(size, sizeof full));
 }
 
 void smatrix_profile(smatrix_t* self, int on) {

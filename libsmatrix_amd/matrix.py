@@ -87,9 +87,14 @@ class SparseMatrix:
         """results=False: no result array is passed (include/smatrix_batch.h: the table ends in the same state, the
         kernels skip the results) and None is returned; out: the caller's own result array (uint32, same length)"""
         x, y = _u32(x), _u32(y)
-        assert x.shape == y.shape
+        if x.shape != y.shape:
+            raise ValueError("x and y must have the same shape")
         if out is not None:
-            assert results and out.dtype == np.uint32 and out.shape == x.shape and out.flags["C_CONTIGUOUS"]
+            # (explicit checks, not asserts: python -O strips those, and a raw pointer goes to C -- ADVICE r5)
+            if not results:
+                raise ValueError("out given with results=False")
+            if not isinstance(out, np.ndarray) or out.dtype != np.uint32 or out.shape != x.shape or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous uint32 array of the batch's shape")
         else:
             out = np.empty_like(x) if results else None
         vv = _u32(v) if v is not None else None
@@ -192,8 +197,8 @@ class SparseMatrix:
     # ---- introspection --------------------------------------------------------
     def stats(self):
         st = _lib.Stats()
-        self._lib.smatrix_stats(self._h, C.byref(st))
-        out = {n: getattr(st, n) for n, t in _lib.Stats._fields_ if t is C.c_uint64}
+        self._lib.smatrix_stats_sz(self._h, C.byref(st), C.sizeof(st))
+        out = {n: getattr(st, n) for n, t in _lib.Stats._fields_ if t is C.c_uint64 or t is C.c_double}
         for i, op in enumerate(("get", "set", "incr", "decr")):
             out["kernel_ms_" + op] = st.kernel_ms[i]
             out["kernel_launches_" + op] = st.kernel_launches[i]
@@ -210,7 +215,8 @@ class SparseMatrix:
 
     def compact(self):
         """file mode: rewrite the backing file without leaked blocks (include/smatrix_batch.h smatrix_compact)"""
-        self._lib.smatrix_compact(self._h)
+        if self._lib.smatrix_compact(self._h) != 0:
+            raise RuntimeError("smatrix_compact did nothing: it is experimental and needs SMATRIX_EXPERIMENTAL=1 in the environment")
 
     def profile(self, on=True):
         self._lib.smatrix_profile(self._h, int(on))

@@ -1,0 +1,178 @@
+"""Round 6 GPU tests (through the C ABI): what VERDICT r5 / ADVICE r5 asked for, and both sides of every switch round 6 added."""
+import os
+import shutil
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def G():
+    from tests.gpu_adapter import GpuMatrix
+    import libsmatrix_amd
+    assert libsmatrix_amd.device_available(), "no HIP device: the product has no CPU fallback"
+    return GpuMatrix
+
+
+# ---- k_grow_rest_lds in time slices -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("slice_cells", ["64", "700", "1000000000"])
+def test_rehash_in_time_slices_is_the_reference_layout(G, oracle_mod, monkeypatch, slice_cells):
+    """A clustered row's displaced cells are re-inserted in K slices of old slot order, each by a workgroup that first enters the
+    cells in front of its slice in ANY order (k_grow_rest_lds).  The byte-identical doublings of round 3 / round 5 -- a run in
+    the middle, a run round the end of the table (wrapped cells: the wave that holds cells of the last run waits for the slice's
+    first wave wherever the cuts fall), a pile behind a run with holes -- with slices of 64 cells (a hundred workgroups per row),
+    of 700 (cuts inside the last run), and one slice per row (the round-5 shape).  src/smatrix.c:383-416."""
+    monkeypatch.setenv("SMATRIX_REST_SLICE", slice_cells)
+    from tests import test_gpu_round3 as r3, test_gpu_round5 as r5
+    for shape in ("run-in-the-middle", "run-round-the-end"):
+        r3.test_chunked_growth_of_a_clustered_row_is_the_reference_layout(G, oracle_mod, monkeypatch, shape, "1")
+    for shape in ("pile-behind-a-run", "run-round-the-end"):
+        r5.test_big_clustered_rows_double_into_the_reference_layout(G, oracle_mod, monkeypatch, shape)
+
+
+# ---- both sides of the switches of round 6 -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("switch", ["SMATRIX_PEND", "SMATRIX_FAR_PLACE", "SMATRIX_GET_SPLIT", "SMATRIX_REST_LDS"])
+@pytest.mark.parametrize("value", ["1", "0"])
+def test_dense_zipf_stream_both_sides_of_a_switch(G, oracle_mod, monkeypatch, switch, value):
+    """Dense Zipf ranks on 16 rows (big clustered rows, far keys by the thousand, rows that double under them: round 5's stream)
+    with each dense-id mechanism of round 6 on and off -- growth that takes the waiting keys in (SMATRIX_PEND), the join's absent
+    keys placed a row at a time (SMATRIX_FAR_PLACE), gets that ask for the next cells and the hint together (SMATRIX_GET_SPLIT),
+    the displaced cells of clustered rows on a bitmap in LDS (SMATRIX_REST_LDS).  Returns, gets, sizes, used counters, cells
+    and the probe invariant are the oracle's either way."""
+    monkeypatch.setenv(switch, value)
+    from tests import test_gpu_round5 as r5
+    r5.test_dense_zipf_stream_with_and_without_the_far_join(G, oracle_mod, monkeypatch, "1")
+
+
+def test_growth_takes_the_waiting_keys_in(G, oracle_mod, monkeypatch):
+    """One row, clustered: 12 000 keys at home (one batch), then batches of new keys that wrap onto the run -- each batch pushes
+    the row over its threshold once or twice, and the keys that wait for the doubling are put into the new table by the kernel
+    that rebuilds it (k_pend_group -> k_grow_lds / k_grow_rest_lds), duplicates of a key within the batch included.  Sizes and
+    used counters are exact after every batch (a key taken in twice, or a ticket lost, would show), cells are the oracle's as a
+    set, no empty cell sits inside a probe sequence, per-key return multisets and gets match.  src/smatrix.c:343-416."""
+    monkeypatch.setenv("SMATRIX_CLUSTERED", "1")
+    rng = np.random.default_rng(2026)
+    g, o = G(), oracle_mod.Oracle()
+    X = 3
+    home = np.arange(1, 12001, dtype=np.uint32)
+    for m in (g, o):
+        m.apply(2, np.full(home.size, X, np.uint32), home, np.ones(home.size, np.uint32))
+    for rnd in range(5):
+        n = 9000                                                     # (the oracle walks every key to the end of the run: sizes that take seconds)
+        # new keys that wrap (multiples of the table sizes in play added to small ids), each named up to three times
+        y = (rng.integers(1, 16000, n) + (1 << rng.integers(15, 21, n))).astype(np.uint32)
+        y = np.concatenate([y, y[: n // 3], y[: n // 7]])
+        rng.shuffle(y)
+        x = np.full(y.size, X, np.uint32)
+        op = 3 if rnd == 3 else 2
+        v = np.full(y.size, 2, np.uint32)
+        a, b = g.apply(op, x, y, v), o.apply(op, x, y, v)
+        kk = y.astype(np.uint64)
+        assert (a[np.lexsort((a, kk))] == b[np.lexsort((b, kk))]).all(), rnd
+        assert g.row_info(X) == o.row_info(X), (rnd, g.row_info(X), o.row_info(X))
+        assert (g.apply(0, x, y) == o.apply(0, x, y)).all(), rnd
+    A, B = np.asarray(g.row_slots(X)), np.asarray(o.row_slots(X))
+    ne = (A[:, 0] != 0) | (A[:, 1] != 0)
+    ka = A[ne]; kb = B[(B[:, 0] != 0) | (B[:, 1] != 0)]
+    ka = ka[np.lexsort((ka[:, 1], ka[:, 0]))]; kb = kb[np.lexsort((kb[:, 1], kb[:, 0]))]
+    assert ka.shape == kb.shape and (ka == kb).all()
+    size = A.shape[0]; pos = np.flatnonzero(ne); empties = np.flatnonzero(~ne)
+    hm = A[pos, 0].astype(np.int64) & (size - 1)
+    nxt = empties[np.searchsorted(empties, hm) % empties.size]
+    assert (((nxt - hm) % size) > ((pos - hm) % size)).all(), "an empty cell inside a probe sequence"
+    assert g.stats()["rows_grown"] >= 2
+    g.close(); o.close()
+
+
+# ---- ADVICE r4 / VERDICT r5 #5: nobody waits for the file with the matrix lock in its hand ---------------------------------------
+def test_a_second_flush_does_not_hold_up_the_callers(G, tmp_path, monkeypatch):
+    """Lock order: the file lock FIRST, then the matrix lock.  A flush in flight writes its snapshot with the file lock alone; a
+    second smatrix_flush that arrived meanwhile used to take the matrix lock and then wait for the file -- every caller of the
+    handle stood behind it for the rest of the write.  Here: 1.6 GB of dirty row tables, fsync on (the write takes a while), the
+    background flusher off; thread A flushes, thread B flushes 30 ms later, and the main thread keeps issuing small get batches
+    (each takes the matrix lock) for as long as A is busy.  No get may wait longer than a fraction of the write.
+    Reference behaviour: the IO thread never blocks callers (src/smatrix.c:929-960)."""
+    monkeypatch.setenv("SMATRIX_FLUSH_MS", "0")
+    monkeypatch.setenv("SMATRIX_FSYNC", "1")
+    path = str(tmp_path / "lockorder.smx")
+    g = G(path)
+    rng = np.random.default_rng(9)
+    rows = 400000                                                    # x 512-cell tables = 1.6 GB
+    for part in range(8):
+        x = np.repeat(np.arange(part * rows // 8, (part + 1) * rows // 8, dtype=np.uint32), 200)
+        y = rng.integers(1, 1 << 30, x.size, dtype=np.uint32)
+        g.m.apply_batch(2, x, y, np.ones(x.size, np.uint32), results=False)
+    qx = np.arange(0, 1024, dtype=np.uint32); qy = np.full(1024, 7, np.uint32)
+    g.m.get_batch(qx, qy)                                            # (warm: buffers, kernels)
+    spans = {}
+
+    def flusher(tag, delay):
+        time.sleep(delay)
+        t0 = time.perf_counter()
+        g.m.flush()
+        spans[tag] = (t0, time.perf_counter())
+
+    ta = threading.Thread(target=flusher, args=("a", 0.0)); tb = threading.Thread(target=flusher, args=("b", 0.03))
+    ta.start(); tb.start()
+    lat = []
+    t_end = time.perf_counter() + 30
+    while ta.is_alive() and time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        g.m.get_batch(qx, qy)
+        lat.append(time.perf_counter() - t0)
+        time.sleep(0.001)
+    ta.join(); tb.join()
+    write = spans["a"][1] - spans["a"][0]
+    assert write > 0.15, ("the first flush must last long enough to tell", write)
+    assert len(lat) >= 10
+    worst = max(lat[1:])                                            # (the first call may have been issued while A snapshot its rows under the lock)
+    assert worst < max(0.05, write / 4), ("a caller waited for the file", worst, write, len(lat))
+    assert g.stats()["file_flushes"] >= 1
+    g.close()
+
+
+def test_a_refused_snapshot_buffer_writes_under_the_lock(G, oracle_mod, tmp_path, monkeypatch):
+    """a flush that cannot get its snapshot buffer on the device writes window by window with the lock held instead
+    of aborting.  SMATRIX_FLUSH_SNAPSHOT_REFUSE=1 forces that path: the file, read by the oracle, holds every cell, and
+    stats.flush_snapshots_refused counts the flushes."""
+    monkeypatch.setenv("SMATRIX_FLUSH_SNAPSHOT_REFUSE", "1")
+    monkeypatch.setenv("SMATRIX_FLUSH_MS", "0")
+    monkeypatch.setenv("SMATRIX_IO_WINDOW_MB", "1")
+    path = str(tmp_path / "refused.smx")
+    g = G(path)
+    rng = np.random.default_rng(4)
+    x = np.repeat(np.arange(0, 20000, dtype=np.uint32), 30); y = rng.integers(1, 1 << 24, x.size, dtype=np.uint32)
+    g.m.incr_batch(x, y, np.ones(x.size, np.uint32))
+    g.m.flush()
+    assert g.stats()["flush_snapshots_refused"] >= 1
+    snap = str(tmp_path / "copy.smx"); shutil.copyfile(path, snap)
+    o = oracle_mod.Oracle(snap)
+    assert (o.apply(0, x, y) >= 1).all() and o.num_rows() == 20000
+    o.close(); g.close()
+
+
+def test_stats_for_an_older_header_and_the_host_time_split(G):
+    """smatrix_stats_sz writes no more than the caller's struct holds (fields are only appended); the appended fields
+    split a write batch's wall time into waiting for the device, device allocations, and the rest."""
+    import ctypes as C
+    from libsmatrix_amd import _lib
+    g = G()
+    x = np.arange(1, 200001, dtype=np.uint32)
+    g.apply(2, x % 977, x, np.ones(x.size, np.uint32))
+    st = g.stats()
+    assert st["write_call_ms"] > 0 and st["write_call_ms"] >= st["write_wait_ms"] >= 0 and st["write_alloc_ms"] >= 0
+    assert st["last_write_call_ms"] <= st["write_call_ms"] + 1e-9
+    buf = (C.c_uint8 * (C.sizeof(_lib.Stats) + 64))()
+    C.memset(buf, 0xAB, len(buf))
+    short = 8 * 29                                                   # an older header: the counters up to flush_snapshots_refused
+    g.m._lib.smatrix_stats_sz(g.m._h, C.cast(buf, C.POINTER(_lib.Stats)), short)
+    assert all(b == 0xAB for b in bytes(buf)[short:]), "bytes beyond the caller's struct were written"
+    assert int.from_bytes(bytes(buf)[:8], "little") == st["rows"]
+    g.close()
