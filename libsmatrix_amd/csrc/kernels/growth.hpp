@@ -160,26 +160,55 @@ __global__ __launch_bounds__(256) void k_grow_plan(Ctl* ctl, GrowTask* tasks, ui
 constexpr uint32_t PEND_MARK = 0xFFFFFFFFu;              // the "old slot" of a key that had none
 __global__ __launch_bounds__(256) void k_pend_group(const Ctl* ctl, GrowTask* tasks, const uint32_t* task_of, const uint2* rec, uint32_t rec_cap,
                                                     const uint32_t* pend_ctl, unsigned long long* hash, uint32_t hmask, uint32_t* keys) {
+  // (places in a bucket are handed out per WORKGROUP and row: a young table's hottest row has 10^5 keys waiting, and as many
+  //  returning atomics on its one counter queued at the memory side -- 1.2 ms for this kernel in the dense stream's third batch)
+  constexpr uint32_t LT = 512;                                             // 2 x the workgroup: the rows its 256 records name
+  __shared__ uint32_t l_task[LT], l_cnt[LT], l_base[LT];
   const uint32_t n = min(pend_ctl[0], rec_cap), n_tasks = aload(&ctl->n_tasks);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint2 r = rec[i];
-    const uint32_t t = task_of[r.x];
-    if (t >= n_tasks) continue;
-    const GrowTask k = tasks[t];
-    if (k.dslot != r.x || k.new_base == 0 || k.pend_cap == 0) continue;    // (a stale entry, a refused task, no bucket)
-    const unsigned long long key = ((unsigned long long)r.x << 32) | r.y;  // (y != 0: never the empty entry)
-    uint32_t e = fmix32(r.x * 0x9E3779B1u ^ r.y * 0x85EBCA77u) & hmask;
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {      // block-uniform
+    for (uint32_t q = threadIdx.x; q < LT; q += blockDim.x) { l_task[q] = 0xFFFFFFFFu; l_cnt[q] = 0; }
+    __syncthreads();
+    const uint32_t i = i0 + threadIdx.x;
     bool mine = false;
-    for (uint32_t guard = 0; guard < 64; guard++) {
-      unsigned long long prev = hash[e];
-      if (prev == 0ull) prev = atomicCAS(&hash[e], 0ull, key);
-      if (prev == 0ull) { mine = true; break; }
-      if (prev == key) break;                                              // another op has named this key
-      e = (e + 1) & hmask;
+    uint32_t t = 0, y = 0, slot = 0, rank = 0, off = 0, cap = 0;
+    if (i < n) {
+      const uint2 r = rec[i];
+      t = task_of[r.x];
+      y = r.y;
+      if (t < n_tasks) {
+        const GrowTask k = tasks[t];
+        if (k.dslot == r.x && k.new_base != 0 && k.pend_cap != 0) {        // (else: a stale entry, a refused task, no bucket)
+          off = k.pend_off; cap = k.pend_cap;
+          const unsigned long long key = ((unsigned long long)r.x << 32) | r.y;      // (y != 0: never the empty entry)
+          uint32_t e = fmix32(r.x * 0x9E3779B1u ^ r.y * 0x85EBCA77u) & hmask;
+          for (uint32_t guard = 0; guard < 64; guard++) {
+            unsigned long long prev = hash[e];
+            if (prev == 0ull) prev = atomicCAS(&hash[e], 0ull, key);
+            if (prev == 0ull) { mine = true; break; }
+            if (prev == key) break;                                        // another op has named this key
+            e = (e + 1) & hmask;
+          }                                                                // (crowded here: the key waits for the retry)
+        }
+      }
     }
-    if (!mine) continue;                                                    // (or the set is crowded here: the key waits for the retry)
-    const uint32_t at = atomicAdd(&tasks[t].n_pend, 1u);
-    if (at < k.pend_cap) keys[k.pend_off + at] = r.y;
+    if (mine) {
+      slot = (t * 0x9E3779B1u) >> 23;                                      // 9 bits
+      for (;;) {
+        const uint32_t prev = atomicCAS(&l_task[slot], 0xFFFFFFFFu, t);
+        if (prev == 0xFFFFFFFFu || prev == t) break;
+        slot = (slot + 1) & (LT - 1);
+      }
+      rank = atomicAdd(&l_cnt[slot], 1u);
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < LT; q += blockDim.x)
+      if (l_task[q] != 0xFFFFFFFFu) l_base[q] = atomicAdd(&tasks[l_task[q]].n_pend, l_cnt[q]);
+    __syncthreads();
+    if (mine) {
+      const uint32_t at = l_base[slot] + rank;
+      if (at < cap) keys[off + at] = y;
+    }
+    __syncthreads();                                                        // (the table is reused by the next trip)
   }
 }
 
@@ -332,7 +361,7 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
       const uint32_t r = l_tab[q];
       const uint64_t c = r == NONE ? 0ull : r >= old_size ? pack_cell(pend[r - old_size], 0u) : l_old[r];
       T[q] = c;
-      if (r != NONE && r >= old_size && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);   // (beyond the lane's budget: remembered)
+      if (r != NONE && home_on && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);   // (beyond the lane's budget: remembered -- the old table's hints died with its block)
       if (bits) {
         const uint64_t hm = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & nmask) == q);
         if ((q & 63u) == 0) hb[q >> 6] = hm;
@@ -940,6 +969,9 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
           const unsigned long long before = atomicOr(&B[z >> 6], bit);
           if ((before | bit) == ~0ull) atomicOr(&S[z >> 12], 1ull << ((z >> 6) & 63u));
           T[z] = cell;
+          // (a cell that ends beyond a lane's budget: the hints of the old table died with its block -- the first op that names the
+          //  key would walk with its wave again, the get behind this batch included; hint_put does nothing without a hint table)
+          if (((z - cell_key(cell)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(cell), z);
           pending = false;
         }
         if (pending) cur = t;                                               // (everything below t is taken: the next look starts there)
@@ -1270,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_grow_zero(const Ctl* ctl, const GrowTas
 // publish the new tables (src/smatrix.c:408-410) and push the old blocks on their classes' stacks
 // (one atomic per class and workgroup; the host sized every stack for this round's pushes beforehand)
 __device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* tasks, DirSlot* dir, uint8_t* arena,
-                                                 FreeLists fl) {
+                                                 FreeLists fl, uint32_t* big_list = nullptr, uint32_t big_cap = 0) {
   __shared__ uint32_t l_want[N_CLASSES], l_at[N_CLASSES];
   const uint32_t n = aload(&ctl->n_tasks);
   for (uint32_t t0 = g.bid * blockDim.x; t0 < n; t0 += g.nb * blockDim.x) {    // block-uniform
@@ -1297,6 +1329,10 @@ __device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* ta
       d.meta = META_USED | META_DIRTY | (lg << META_LG_SHIFT);
       d.base = k.new_base;
       d.used = count;
+      if (big_list && lg == FAR_ROW_LG) {             // the row joins the rows the far join scans (k_far_rows: big_list)
+        const uint32_t at = atomicAdd(&big_list[0], 1u);
+        if (at < big_cap) big_list[1u + at] = k.dslot;
+      }
       if (lg >= BIG_LG) {
         const uint32_t cap = (1u << lg) / 2u + 1u;
         subs_init(row_subs(arena, k.new_base, lg), cap > count ? cap - count : 0u);
@@ -1319,8 +1355,8 @@ __device__ __forceinline__ void grow_commit_body(VGrid g, Ctl* ctl, GrowTask* ta
   }
 }
 __global__ __launch_bounds__(256) void k_grow_commit(Ctl* ctl, GrowTask* tasks, DirSlot* dir, uint8_t* arena,
-                                                     FreeLists fl) {
-  grow_commit_body(SMX_VG, ctl, tasks, dir, arena, fl);
+                                                     FreeLists fl, uint32_t* big_list, uint32_t big_cap) {
+  grow_commit_body(SMX_VG, ctl, tasks, dir, arena, fl, big_list, big_cap);
 }
 
 // The at-home bitmaps of all rows of >= 2^HOME_LG cells, rebuilt from the tables as they stand: run once when a matrix turns

@@ -181,6 +181,8 @@ constexpr uint32_t FAR_ROW_LG = SMX_FAR_ROW_LG;           // ... of rows from 81
 constexpr uint32_t FAR_UNIT_WORDS = 1u << (FAR_UNIT_LG - 6);
 constexpr uint32_t FAR_NOT_FOUND = 0xFFFFFFFFu;
 __device__ inline uint32_t far_hash(uint32_t base, uint32_t Y) { return fmix32(base * 0x9E3779B1u + Y * 0x85EBCA77u + 0x27d4eb2fu); }
+constexpr uint32_t FAR_BLOOM_LG = 23;
+__device__ inline uint32_t far_bloom_bit(uint32_t base, uint32_t Y) { return fmix32(base * 0x85EBCA77u ^ Y * 0xC2B2AE3Du ^ 0x165667B1u) >> (32 - FAR_BLOOM_LG); }
 // the entry of {base, Y}, or nullptr (linear probing; a never-used entry ends the search)
 __device__ inline uint4* far_entry(uint4* tab, uint32_t tmask, uint32_t base, uint32_t Y) {
   uint32_t e = far_hash(base, Y) & tmask;
@@ -1693,13 +1695,23 @@ __global__ __launch_bounds__(AGG_THREADS) __attribute__((amdgpu_num_sgpr(SMX_AGG
 // ---- the far join's kernels (see "far join" above) ---------------------------------------------------------------------------
 // k_far_rows: every row of >= 2^FAR_ROW_LG cells takes its units (one atomic add: the order does not matter), fills the unit ->
 // row map and enters F as {row block, 0} -> first unit.  A row that does not fit the capacities is left out.
+// unit_info (round 6): per unit {row block, log2 size << 24 | the unit's place in its row} -- what k_far_scan needs of a unit's row in
+// ONE load (it used to go unit -> directory slot -> the row's entry of F before it could ask for a cell); y = 2^32-1: the row did not fit
 __global__ __launch_bounds__(256) void k_far_rows(Ctl* ctl, const DirSlot* dir, uint32_t dir_size, uint32_t* unit_row, uint32_t cap_units, uint4* tab,
-                                                  uint32_t tmask) {
+                                                  uint32_t tmask, uint2* unit_info, uint32_t* big_list, uint32_t big_cap, uint32_t from_list) {
+  // big_list (round 6): the directory slots of the rows of >= 2^FAR_ROW_LG cells, [0] = their number.  The pass over the whole
+  // directory (64 MB per dense-id batch to find 4 000 rows: 90 us) REBUILDS it; from then on k_grow_commit appends every row that
+  // reaches 2^FAR_ROW_LG cells (rows never shrink or go away) and this kernel walks the list (from_list) -- until the directory
+  // is rebuilt (its slots move) or a file is loaded.  A row the list misses is only not in the join: its far ops walk as before.
   const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t h0 = blockIdx.x * blockDim.x; h0 < dir_size; h0 += gridDim.x * blockDim.x) {      // (block-uniform: dir_size is a multiple of 256)
-    const uint32_t h = h0 + threadIdx.x;
-    const DirSlot d = dir[h];
+  const uint32_t n_src = from_list ? min(big_list[0], big_cap) : dir_size;
+  for (uint32_t h0 = blockIdx.x * blockDim.x; h0 < n_src; h0 += gridDim.x * blockDim.x) {      // (block-uniform)
+    const uint32_t i_src = h0 + threadIdx.x;
+    const uint32_t h = from_list ? (i_src < n_src ? big_list[1u + i_src] : 0xFFFFFFFFu) : i_src;
+    DirSlot d = {0, 0, 0, 0};
+    if (h != 0xFFFFFFFFu) d = dir[h];
     const bool big = (d.meta & META_USED) && d.base != 0 && meta_lg(d.meta) >= FAR_ROW_LG;
+    if (big && !from_list && big_list) { const uint32_t at = atomicAdd(&big_list[0], 1u); if (at < big_cap) big_list[1u + at] = h; }
     const uint32_t units = big ? 1u << (meta_lg(d.meta) - FAR_UNIT_LG) : 0u;
     // one reservation per WAVE (10^5 rows adding to one word one by one were 1 ms of every batch)
     uint32_t incl = units;
@@ -1730,8 +1742,13 @@ __global__ __launch_bounds__(256) void k_far_rows(Ctl* ctl, const DirSlot* dir, 
     // the unit -> row map, a row at a time with the whole wave (the lane of a 2^21-cell row wrote its 4096 entries alone: 1 ms)
     for (uint64_t todo = bm; todo; todo &= todo - 1) {                     // (wave-uniform)
       const int src = __ffsll((unsigned long long)todo) - 1;
-      const uint32_t f = (uint32_t)__shfl((int)first, src), n = (uint32_t)__shfl((int)units, src), hh = h0 + (threadIdx.x & ~63u) + (uint32_t)src;
-      for (uint32_t u = lane; u < n && (uint64_t)f + u < cap_units; u += 64) unit_row[f + u] = hh;           // (every unit below the capacity names ITS row)
+      const uint32_t f = (uint32_t)__shfl((int)first, src), n = (uint32_t)__shfl((int)units, src), hh = (uint32_t)__shfl((int)h, src);
+      const uint32_t rb = (uint32_t)__shfl((int)d.base, src), rlg = (uint32_t)__shfl((int)meta_lg(d.meta), src);
+      const bool fits = (uint64_t)f + n <= cap_units;
+      for (uint32_t u = lane; u < n && (uint64_t)f + u < cap_units; u += 64) {
+        unit_row[f + u] = hh;           // (every unit below the capacity names ITS row)
+        unit_info[f + u] = uint2{rb, fits ? (rlg << 24) | u : 0xFFFFFFFFu};
+      }
     }
     if (big && (uint64_t)first + units <= cap_units) far_insert(tab, tmask, d.base, 0u, first);
   }
@@ -1741,7 +1758,9 @@ __global__ __launch_bounds__(256) void k_far_rows(Ctl* ctl, const DirSlot* dir, 
 // going to find out again: nothing changes in between) enter F.  `limit`: ops beyond it are not entered (the table would fill up).
 __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, const uint32_t* idx,
                                                   const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t st, uint4* tab,
-                                                  uint32_t tmask, uint32_t limit, uint32_t all_far) {
+                                                  uint32_t tmask, uint32_t limit, uint32_t all_far, uint32_t* bloom) {
+  // bloom (round 6): one bit per key of F in a table of 2^FAR_BLOOM_LG bits (1 MB: it stays in L2) -- k_far_scan asks it before
+  // it looks a displaced cell's key up in F (9 M look-ups in a 64 MB table per dense-id batch, 24 of 25 for keys F does not hold)
   // all_far (the walkers of a cold round: keys known absent whose home cell is taken): every listed key of an indexed row enters F,
   // however short its probe is now -- thousands of new keys of one hot row end their walks on the same few empty cells, and the
   // ones that were not in F took them by compare-and-swap, one winner per cell and turn: 20 000 trips of 1.3 M clock ticks on
@@ -1761,7 +1780,11 @@ __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32
       if (cell_key(c) == Y || c == 0) { far = false; break; }
       pos = (pos + 1) & mask;
     }
-    if (far && !far_insert(tab, tmask, s.z, Y, FAR_NOT_FOUND)) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
+    if (far) {
+      if (!far_insert(tab, tmask, s.z, Y, FAR_NOT_FOUND)) reinterpret_cast<ArenaHead*>(arena)->far_overflow = 1;
+      const uint32_t hb = far_bloom_bit(s.z, Y);
+      atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
+    }
   }
   // (ops beyond the limit are not in the table: two ops naming one new key could then take different paths -- no claimed inserts)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1774,18 +1797,18 @@ __global__ __launch_bounds__(256) void k_far_keys(Ctl* ctl, DirSlot* dir, uint32
 // the unit's count of free cells, and every displaced cell's slot into its key's entry of F, if it has one.
 __global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot* dir, const uint32_t* unit_row, uint32_t cap_units, uint8_t* arena,
                                                   uint4* tab, uint32_t tmask, unsigned long long* occ, uint32_t* zeros, unsigned long long* occ0, uint32_t* clm,
-                                                  uint32_t* rcnt) {
+                                                  uint32_t* rcnt, const uint32_t* bloom, const uint2* unit_info) {
   // rcnt (round 6, k_far_absent / k_far_place): per unit, the absent keys of the row that begins there -- zeroed here
   const uint32_t n_units = min(aload(&ctl->n_units), cap_units);
   const uint32_t lane = threadIdx.x & 63u, nwaves = (gridDim.x * blockDim.x) >> 6;
   if (rcnt && blockIdx.x == 0 && threadIdx.x == 0) rcnt[cap_units] = 0;
   for (uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < n_units; u += nwaves) {     // (wave-uniform)
-    const DirSlot d = dir[unit_row[u]];
-    const uint32_t mask = (1u << meta_lg(d.meta)) - 1u;
-    const uint4* row = far_entry(tab, tmask, d.base, 0u);                  // (a row that did not fit whole has no entry: its units are skipped)
+    const uint2 ui = unit_info[u];
+    struct { uint32_t base; } d = {ui.x};
+    const uint32_t mask = (1u << (ui.y >> 24)) - 1u;
     if (rcnt && lane == 0) rcnt[u] = 0;
-    if (!row) { if (lane == 0) zeros[u] = 0xFFFFFFFFu; continue; }
-    const uint32_t p0 = (u - row->z) << FAR_UNIT_LG;
+    if (ui.y == 0xFFFFFFFFu) { if (lane == 0) zeros[u] = 0xFFFFFFFFu; continue; }      // (a row that did not fit whole has no entry in F: its units are skipped)
+    const uint32_t p0 = (ui.y & 0xFFFFFFu) << FAR_UNIT_LG;
     const uint64_t* cells = row_cells(arena, d.base) + p0;
     uint64_t c[FAR_UNIT_WORDS];
 #pragma unroll
@@ -1799,8 +1822,11 @@ __global__ __launch_bounds__(256) void k_far_scan(const Ctl* ctl, const DirSlot*
       free_cells += 64u - (uint32_t)__popcll(m);
       if (lane == 0) { occ[(size_t)u * FAR_UNIT_WORDS + q] = m; occ0[(size_t)u * FAR_UNIT_WORDS + q] = m; clm[(size_t)u * FAR_UNIT_WORDS + q] = 0; }
       if (taken && (key & mask) != p) {
-        uint4* e = far_entry(tab, tmask, d.base, key);
-        if (e) e->z = p;
+        const uint32_t hb = far_bloom_bit(d.base, key);
+        if ((bloom[hb >> 5] >> (hb & 31u)) & 1u) {
+          uint4* e = far_entry(tab, tmask, d.base, key);
+          if (e) e->z = p;
+        }
       }
     }
     if (lane == 0) zeros[u] = free_cells;

@@ -102,6 +102,29 @@ inline void scratch_pool_trim() {
   if (hipMemPool_t pool = scratch_pool()) { (void)hipMemPoolTrimTo(pool, 0); (void)hipGetLastError(); }
 }
 
+// Buffers that DevBuf::need has outgrown are not handed back on the spot: hipFree waits for the device and for the driver
+// (1.7 ms for the ten buffers the dense stream's third batch replaces -- in the middle of its rounds).  They wait here, at most
+// GRAVEYARD_MAX bytes of them (need() doubles, so they add up to less than what replaced them), until a matrix is closed, an
+// allocation fails, or smatrix_release_cached_memory is called.
+struct Graveyard {
+  static constexpr size_t GRAVEYARD_MAX = (size_t)8 << 30;
+  std::mutex mu;
+  std::vector<std::pair<void*, size_t>> dead;
+  size_t bytes = 0;
+  void bury(void* p, size_t n) {
+    std::unique_lock<std::mutex> g(mu);
+    dead.push_back({p, n});
+    bytes += n;
+    if (bytes > GRAVEYARD_MAX) { g.unlock(); empty(); }
+  }
+  void empty() {
+    std::vector<std::pair<void*, size_t>> d;
+    { std::lock_guard<std::mutex> g(mu); d.swap(dead); bytes = 0; }
+    for (auto& e : d) (void)dev_free(e.first);
+  }
+};
+inline Graveyard& graveyard() { static Graveyard g; return g; }
+
 template <typename T>
 inline void dev_malloc(T** p, size_t bytes) {
   struct Tick { double t0 = mono_s(); size_t b; ~Tick() { AllocClock& c = alloc_clock(); c.n_alloc++; c.s_alloc += mono_s() - t0;
@@ -109,6 +132,7 @@ inline void dev_malloc(T** p, size_t bytes) {
   tick.b = bytes;
   if (hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess) return;
   (void)hipGetLastError();
+  graveyard().empty();
   chunk_pool_trim();
   scratch_pool_trim();
   HIP_OK(hipMalloc(reinterpret_cast<void**>(p), bytes));
@@ -291,7 +315,7 @@ struct DevBuf {
   bool pooled = false;                 // allocated with hipMallocAsync (need_on)
   void need(size_t n) {
     if (n <= cap) return;
-    if (p) HIP_OK(dev_free(p));
+    if (p) graveyard().bury(p, cap * sizeof(T));      // (not freed here: see Graveyard)
     size_t c = std::max<size_t>(n, cap * 2);
     dev_malloc(&p, c * sizeof(T));
     cap = c;
@@ -696,6 +720,10 @@ struct Matrix {
   bool pend_on = true;                  // SMATRIX_PEND=0: the keys that wait for a doubling go in through the retry, as in round 5
   bool pend_armed = false;              // the prep that has just been enqueued left records (the growth round that follows groups them)
   uint32_t pend_est = 0;                // ... about so many
+  DevBuf<uint32_t> big_list;            // [0] = n, then the directory slots of the rows of >= 2^FAR_ROW_LG cells (k_far_rows rebuilds it, k_grow_commit appends)
+  bool big_list_valid = false;          // ... complete for the directory as it stands (not after a rebuild of the directory or a file load)
+  DevBuf<uint2> far_unit_info;          // per unit: its row's block, size and its place in the row (k_far_rows -> k_far_scan)
+  DevBuf<uint32_t> far_bloom;           // one bit per key of F (k_far_keys -> k_far_scan)
   DevBuf<uint32_t> far_rcnt, far_bucket, far_prows;   // k_far_absent / k_far_place: absent keys per row (at its first unit; + the row count), their entries of F, the rows that have any
   bool far_place = true;                // SMATRIX_FAR_PLACE=0: the keys the join calls absent are inserted one by one by the pass (claims by rank), as in round 5
   uint32_t far_tab_lg = 0;              // what ArenaHead's far fields name
@@ -798,7 +826,9 @@ void ensure_arena_free(Matrix* m, uint64_t units, hipStream_t s) {
   m->arena.grow_to(target, m->arena_next * UNIT_BYTES, s);
 }
 
+constexpr uint32_t BIG_LIST_CAP = 1u << 20;
 void grow_directory(Matrix* m, uint32_t factor, hipStream_t s) {
+  m->big_list_valid = false;                                // (directory slots move)
   uint64_t ns64 = (uint64_t)m->dir_size * factor;
   if (ns64 > (1ull << 31)) smx_die("directory too large");
   uint32_t ns = (uint32_t)ns64;
@@ -883,7 +913,7 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
     // the first join of this matrix: how many rows and units there are is counted once, with a read-back
     HIP_OK(hipMemsetAsync(&m->d_ctl->n_big, 0, 8, s));
     hipLaunchKernelGGL(k_far_rows, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size, (uint32_t*)nullptr, 0u,
-                       (uint4*)nullptr, 0u);
+                       (uint4*)nullptr, 0u, (uint2*)nullptr, (uint32_t*)nullptr, 0u, 0u);
     HIP_OK(hipGetLastError());
     uint32_t two[2] = {0, 0};
     HIP_OK(hipMemcpyAsync(two, &m->d_ctl->n_big, 8, hipMemcpyDeviceToHost, s));
@@ -894,7 +924,7 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
   const uint32_t cap_units = (uint32_t)std::min<uint64_t>(m->arena.mapped >> (FAR_UNIT_LG + 3), (uint64_t)m->far_units_seen * 5 / 4 + 32768);
   uint32_t lg = 16;
   while (lg < 23 && (1ull << lg) < 4ull * est_nd + 2ull * cap_rows) lg++;
-  m->far_unit_row.need(cap_units);
+  m->far_unit_row.need(cap_units); m->far_unit_info.need(cap_units);
   const bool moved = m->far_tab.cap < ((size_t)1 << lg) || m->far_occ.cap < (size_t)cap_units * FAR_UNIT_WORDS || m->far_zeros.cap < cap_units;
   m->far_tab.need((size_t)1 << lg); m->far_occ.need((size_t)cap_units * FAR_UNIT_WORDS); m->far_zeros.need(cap_units);
   m->far_occ0.need((size_t)cap_units * FAR_UNIT_WORDS); m->far_clm.need((size_t)cap_units * FAR_UNIT_WORDS);      // (they move with far_occ)
@@ -913,16 +943,23 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
   HIP_OK(hipMemsetAsync(m->far_tab.p, 0, (size_t)16 << lg, s));
   arena_head_set(m, offsetof(ArenaHead, far_overflow), 0u, s);
   HIP_OK(hipMemsetAsync(&m->d_ctl->n_big, 0, 8, s));       // n_big, n_units
-  hipLaunchKernelGGL(k_far_rows, dim3(std::min<uint32_t>(blocks_for(m->dir_size), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size, m->far_unit_row.p, cap_units,
-                     m->far_tab.p, tmask);
+  // (the rows of >= 2^FAR_ROW_LG cells: by the list k_grow_commit keeps once a pass over the directory has built it)
+  m->big_list.need(BIG_LIST_CAP + 1);
+  const bool by_list = m->big_list_valid;
+  if (!by_list) HIP_OK(hipMemsetAsync(m->big_list.p, 0, 4, s));
+  hipLaunchKernelGGL(k_far_rows, dim3(std::min<uint32_t>(blocks_for(by_list ? std::max<uint32_t>(m->far_rows_seen * 2u, 4096u) : m->dir_size), 4096)), dim3(256), 0, s, m->d_ctl,
+                     m->d_dir, m->dir_size, m->far_unit_row.p, cap_units, m->far_tab.p, tmask, m->far_unit_info.p, m->big_list.p, BIG_LIST_CAP, by_list ? 1u : 0u);
+  m->big_list_valid = true;
   DBG_STEP(m, s, "k_far_rows");
+  m->far_bloom.need((size_t)1 << (FAR_BLOOM_LG - 5));
+  HIP_OK(hipMemsetAsync(m->far_bloom.p, 0, (size_t)4 << (FAR_BLOOM_LG - 5), s));
   hipLaunchKernelGGL(k_far_keys, dim3(std::min<uint32_t>(blocks_for(est_nd), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, dl, x, y,
-                     m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u, all_far ? 1u : 0u);
+                     m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u, all_far ? 1u : 0u, m->far_bloom.p);
   DBG_STEP(m, s, "k_far_keys");
   const bool place = m->far_place && !all_far;
   if (place) { m->far_rcnt.need((size_t)cap_units + 1); m->far_bucket.need((size_t)cap_units * FAR_BUCKET_PER_UNIT); m->far_prows.need(cap_rows); }
   hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 32768)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_unit_row.p, cap_units,
-                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p, place ? m->far_rcnt.p : nullptr);
+                     m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p, place ? m->far_rcnt.p : nullptr, m->far_bloom.p, m->far_unit_info.p);
   DBG_STEP(m, s, "k_far_scan");
   if (place) {
     // the keys the scan has not found are placed a row at a time (k_far_place) before the pass looks for them
@@ -1174,7 +1211,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     HIP_OK(hipStreamWaitEvent(s, m->ev_join, 0));
   }
   hipLaunchKernelGGL(k_grow_commit, dim3(std::min<uint32_t>(blocks_for(nt), 1024)), dim3(256), 0, s,
-                     m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl);
+                     m->d_ctl, m->tasks.p, m->d_dir, m->arena.base, m->fl, m->big_list_valid ? m->big_list.p : nullptr, BIG_LIST_CAP);
   HIP_OK(hipGetLastError());
   DBG_STEP(m, s, "k_grow_commit");
   if (m->trace_rounds && nt > 1000 && !spec) {      // who grows?  (cells moved, by log2 of the old row size)
@@ -2532,7 +2569,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
       delete static_cast<HostPipe*>(m->host_pipe);
-      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release(); m->far_rcnt.release(); m->far_bucket.release(); m->far_prows.release();
+      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release(); m->far_rcnt.release(); m->far_bucket.release(); m->far_prows.release(); m->far_bloom.release(); m->far_unit_info.release(); m->big_list.release();
       m->pend_rec.release(); m->pend_keys.release(); m->task_of.release(); m->pend_ctl.release(); m->pend_hash.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
@@ -2540,6 +2577,7 @@ void smatrix_close(smatrix_t* self) {
       m->cold_set.release(); m->cold_keys[0].release(); m->cold_keys[1].release(); m->cold_keys[2].release();
       m->cold_idx[0].release(); m->cold_idx[1].release(); m->cold_zero.release();
       m->fx_cnt.release(); m->fx_cur.release(); m->fx_pos.release(); m->fx_touched.release(); m->fx_where.release(); m->fx_grouped.release(); m->fx_rank.release(); m->fx_excl.release(); m->fx_tiles.release();
+      graveyard().empty();                         // (the buffers this and other matrices of the process have outgrown)
       m->tasks.release(); m->klist.release(); m->rebal.release(); m->map_old.release(); m->map_new.release(); m->disp_mask.release(); m->rest_tab.release(); m->cellp.release();
       m->sx.release(); m->sy.release(); m->sv.release(); m->so.release(); m->soff.release(); m->big.release(); m->seg.release(); m->ent_idx.release();
       get_timing_resolve(m, 0);
@@ -3124,6 +3162,7 @@ int smatrix_reserve(smatrix_t* self, uint64_t bytes) {
 
 // physical chunks kept from closed matrices (ChunkPool) go back to the driver now
 void smatrix_release_cached_memory(void) {
+  graveyard().empty();
   chunk_pool().trim();
   int dev = 0;
   hipMemPool_t pool = nullptr;

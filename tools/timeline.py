@@ -21,7 +21,7 @@ for t in tr[start:start + 200]:
     dur = (int(t['End_Timestamp']) - int(t['Start_Timestamp'])) / 1e3
     print("%9.1f us  +%8.1f  %-28s grid=%s" % ((int(t['Start_Timestamp']) - t0) / 1e3, dur, n[:28], t['Grid_Size_X']))
     agg[n] = agg.get(n, 0) + dur
-    if 'k_apply<0' in n:
+    if 'k_apply<0' in n or 'k_get_clu' in n:
         end = int(t['End_Timestamp']); break
 print("step span %.1f us; kernel time by name:" % ((end - t0) / 1e3))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]): print("   %-30s %9.1f us" % (k, v))
