@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SMATRIX_LIB") or os.path.join(HERE, "lib", "smatrix.so")   # override: experiments only
+LIB_PATH = os.path.join(HERE, "lib", "smatrix.so")
 CSRC = os.path.join(HERE, "csrc")
 
 u32p = C.POINTER(C.c_uint32)

@@ -63,7 +63,7 @@ inline void chunk_pool_trim();
 struct AllocClock { uint64_t n_alloc = 0, n_free = 0; double s_alloc = 0, s_free = 0; };
 inline AllocClock& alloc_clock() { static thread_local AllocClock c; return c; }
 inline double mono_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
-inline bool trace_alloc() { static const bool on = getenv("SMATRIX_TRACE_ALLOC") != nullptr; return on; }
+inline bool trace_alloc() { static const bool on = getenv("SMATRIX_TRACE_ROUNDS") && *getenv("SMATRIX_TRACE_ROUNDS") == '3'; return on; }   // (SMATRIX_TRACE_ROUNDS=3: ... and a line per device allocation / free)
 inline hipError_t dev_free(void* p) {
   const double t0 = mono_s();
   const hipError_t e = hipFree(p);
@@ -600,7 +600,8 @@ struct Matrix {
   DevBuf<uint32_t> map_old, map_new;
   DevBuf<unsigned long long> disp_mask; // per old chunk of a growth round: its displaced cells (k_grow_move_home -> k_grow_rest_lds)
   DevBuf<uint32_t> rest_tab;            // k_grow_rest_plan: {slices, then per slice: task, slice | slices of the row << 16}
-  uint32_t rest_slice_cells = REST_SLICE_CELLS, rest_grid = 768;     // (SMATRIX_REST_SLICE / SMATRIX_REST_GRID: measurements)
+  uint32_t rest_slice_cells = REST_SLICE_CELLS;     // SMATRIX_REST_SLICE (tests: slices of 64 cells, one slice per row)
+  static constexpr uint32_t rest_grid = 768;        // (swept 256..1536 with slices of 256..2048 cells: 6.26-6.52 ms per dense-id step, flat)
   DevBuf<uint64_t> cellp;
   DevBuf<uint32_t> sx, sy, sv, so;      // staging for the host-pointer API
   DevBuf<uint64_t> soff;
@@ -630,7 +631,7 @@ struct Matrix {
   struct TimedLaunch { hipEvent_t e0, e1; uint32_t n; };
   std::deque<TimedLaunch> get_pending;  // profiled get launches whose events have not been read yet (get_timing_resolve)
   std::vector<hipEvent_t> ev_free;
-  bool grow_fork = true;                // SMATRIX_GROW_FORK=0: everything of a growth round on the caller's stream (see grow_rows)
+  static constexpr bool grow_fork = true;   // (the chunked passes of a growth round on a helper stream beside the in-LDS rehashes: see grow_rows)
   hipStream_t helper = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
@@ -693,19 +694,19 @@ struct Matrix {
   // clustered; SMATRIX_HINT_LG (0: no hints)
   uint4* d_hints = nullptr;
   uint32_t hint_lg = 22;
-  uint32_t wpo_max = 1u << 22;          // retry lists up to this length run a wave per op on clustered tables (SMATRIX_WPO_MAX)
+  static constexpr uint32_t wpo_max = 1u << 22;   // retry lists up to this length run a wave per op on clustered tables
   uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
-  bool retry_far = true;                // SMATRIX_RETRY_FAR=0: the long retry lists of a clustered table in host-driven rounds a wave per op without the far join
-  bool small_first = true;              // SMATRIX_SMALL_FIRST=0: the cold rounds of a clustered table take their keys in list order (one launch per round)
-  bool retry_split = true;              // SMATRIX_RETRY_SPLIT=0: the retry of a clustered table a wave per op in one launch
-  bool absent_split = true;             // SMATRIX_ABSENT_SPLIT=0: the clustered folding kernel keeps one deferred list
+  static constexpr bool retry_far = true;   // the long retry lists of a clustered table in host-driven rounds go through a far join of their own
+  static constexpr bool small_first = true; // the cold rounds of a clustered table take the keys below their row's size first (list order: 88 vs 72.6 ms)
+  static constexpr bool retry_split = true; // the retry of a clustered table in two halves: k_apply_short, then a wave per op over the rest (0.78 -> 0.66 ms)
+  static constexpr bool absent_split = true;   // the clustered folding kernel keeps two deferred lists (8.5 -> 7.9 ms)
   unsigned long long* rest_dbg = nullptr; uint32_t rest_dbg_mode = 0; uint64_t rest_dbg_from = 0;   // SMATRIX_REST_DBG (measurement runs: k_grow_rest_lds)
-  bool get_split = true;                // SMATRIX_GET_SPLIT=0: gets of a clustered table a lane per op in one pass (k_apply<GET, hints>), as in round 5
+  static constexpr bool get_split = true;   // gets of a clustered table ask for the next cells and the hint in one trip (k_get_clu: 0.90 -> 0.80 ms)
   bool rest_lds = true;                 // SMATRIX_REST_LDS=0: clustered rows' displaced cells move by priority probing alone (k_grow_move_rest), as in round 4
   void* host_pipe = nullptr;            // HostPipe: the staging of large host-pointer batches (smatrix_apply_batch and friends)
   // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
   bool far_join = true;
-  bool far_lanes = false;               // SMATRIX_FAR_LANES=1 (measurements): the pass in front of prep a lane per op, every lane walking the occupancy
+  static constexpr bool far_lanes = false;  // (rejected #48: the pass in front of prep a lane per op, every lane walking the occupancy
                                         // words itself -- slower (4.0 against 2.8 ms per dense-id batch: a wave's trip takes as long as its slowest lane)
   DevBuf<uint4> far_tab;
   DevBuf<uint32_t> far_unit_row, far_zeros;
@@ -736,9 +737,9 @@ struct Matrix {
                                         // 0.036 against 0.126 s.  The price is 0.12 ms of de-duplication that finds nothing in batch 2 of config 2.)
   DevBuf<unsigned long long> cold_set;
   DevBuf<uint32_t> cold_idx[2], cold_zero;   // the walks of a cold round through the far join: the list 0..n-1, what the pass leaves, zeroed amounts
-  uint32_t cold_far_max = 1u << 20;     // ... in rounds of up to this many keys (SMATRIX_COLD_FAR_MAX): the early rounds' millions of keys sit in small rows, a lane walks them faster
-  bool cold_all_far = true;             // SMATRIX_COLD_ALL_FAR=0: only the walkers with a long probe enter the join's table (as in a steady batch)
-  bool cold_far = true;                 // SMATRIX_COLD_FAR=0: the walks of a clustered table's cold rounds a wave per key (k_insert_keys)
+  static constexpr uint32_t cold_far_max = 1u << 20;   // ... in rounds of up to this many keys: the early rounds' millions of keys sit in small rows, a lane walks them faster
+  static constexpr bool cold_all_far = true;   // every walker of an indexed row enters the join's table (only the long probes: 29 vs 22 ms)
+  static constexpr bool cold_far = true;    // the walks of a clustered table's cold rounds go through the far join (a wave per key: 37 vs 69 ms)
   DevBuf<unsigned long long> cold_keys[3];   // the distinct pending keys, packed; what a round leaves deferred
 };
 
@@ -1738,8 +1739,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
       }
       far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(est_far, cur_n));
       if (far_joined && !m->far_lanes) {
-        static const uint32_t wg_env = getenv("SMATRIX_WPO_GRID") ? (uint32_t)strtoul(getenv("SMATRIX_WPO_GRID"), nullptr, 10) : 65536u;
-        const dim3 wgrid(wg_env);
+        const dim3 wgrid(65536);
         if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
         else hipLaunchKernelGGL((k_apply_wpo_far<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
       } else if (far_joined) {
@@ -1779,8 +1779,7 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         // the retry in two halves (k_apply_short): a lane per op for what is short again, then a wave per op over the rest; the
         // list that is left ends up in the buffer the retry READ, so the round's parity moves on by one (below)
         uint32_t* dl0 = dl;
-        static const uint32_t wg2_env = getenv("SMATRIX_WPO_GRID2") ? (uint32_t)strtoul(getenv("SMATRIX_WPO_GRID2"), nullptr, 10) : 65536u;
-        const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * (64 / SMX_WPO_OPS)), wg2_env));
+        const dim3 wgrid(std::min<uint32_t>(blocks_for((uint64_t)est_nd * (64 / SMX_WPO_OPS)), 65536));
         switch (op) {
           case OP_SET:  hipLaunchKernelGGL((k_apply_short<OP_SET>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
           case OP_INCR: hipLaunchKernelGGL((k_apply_short<OP_INCR>), rgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dl1, m->in_stride); break;
@@ -2386,8 +2385,38 @@ int smatrix_device_available(void) {
   return n > 0;
 }
 
+// Every SMATRIX_* variable the library reads (INTEGRATION.md "Switches" has one line and one test for each).  A variable that
+// is set but not in this list -- a typo, or a switch of an earlier round that is gone -- gets ONE warning per process.
+static const char* const KNOWN_SWITCHES[] = {
+    "SMATRIX_BULK", "SMATRIX_BULK_MIN", "SMATRIX_BULK_PRESIZE_MIN", "SMATRIX_BULK_SHARE", "SMATRIX_CHUNK_POOL_GB", "SMATRIX_CLUSTERED", "SMATRIX_COLD_MIN",
+    "SMATRIX_COLD_SHARE", "SMATRIX_COMPACT_AT_CLOSE", "SMATRIX_DEVICE", "SMATRIX_EXPERIMENTAL", "SMATRIX_FAR_JOIN", "SMATRIX_FAR_PLACE", "SMATRIX_FLUSH_EVERY",
+    "SMATRIX_FLUSH_MS", "SMATRIX_FLUSH_SNAPSHOT_MB", "SMATRIX_FLUSH_SNAPSHOT_REFUSE", "SMATRIX_FSYNC", "SMATRIX_HINT_LG", "SMATRIX_HIP_LIB", "SMATRIX_HOST_CHUNK_LG",
+    "SMATRIX_IO_THREADS", "SMATRIX_IO_WINDOW_MB", "SMATRIX_NO_VMM", "SMATRIX_PEND", "SMATRIX_RCCL_LIB", "SMATRIX_REST_LDS", "SMATRIX_REST_SLICE", "SMATRIX_SCALAR_CACHE",
+    "SMATRIX_SCALAR_CACHE_CAP", "SMATRIX_SCRATCH_POOL", "SMATRIX_SET_LOCATE", "SMATRIX_SHARD_FORCE_RCCL", "SMATRIX_SHARD_PLACE", "SMATRIX_SHARD_SHM_MB",
+    "SMATRIX_SHARD_TRANSPORT", "SMATRIX_SPEC", "SMATRIX_SPEC_TINY", "SMATRIX_TRACE_ROUNDS",
+    "SMATRIX_SHARD_HOST_STAGED",        // (read by libsmatrix_amd/sharded.py, the torch.distributed router: test rigs with two ranks on one GPU)
+#ifdef SMX_MEASURE
+    "SMATRIX_DBG_AFTER", "SMATRIX_REST_DBG", "SMATRIX_REST_DBG_FROM",
+#endif
+};
+extern "C" char** environ;
+static void warn_unknown_switches() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (char** e = environ; e && *e; e++) {
+      if (strncmp(*e, "SMATRIX_", 8) != 0) continue;
+      const char* eq = strchr(*e, '=');
+      const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+      bool known = false;
+      for (const char* k : KNOWN_SWITCHES) known |= strlen(k) == len && strncmp(k, *e, len) == 0;
+      if (!known) fprintf(stderr, "libsmatrix: the environment sets %.*s, which this library does not read (INTEGRATION.md lists its switches)\n", (int)len, *e);
+    }
+  });
+}
+
 // src/smatrix.c:74-111
 smatrix_t* smatrix_open(const char* fname) {
+  warn_unknown_switches();
   if (!smatrix_device_available()) {
     fprintf(stderr, "libsmatrix: no HIP device available (this build has no CPU fallback)\n");
     return nullptr;
@@ -2418,7 +2447,6 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_SCALAR_CACHE_CAP")) m->cache.shard_cap = std::max<size_t>(4, std::min<size_t>(strtoull(a, nullptr, 10), CellCache::SLOTS / 2));   // (tests: constant recycling)
   HIP_OK(hipEventCreate(&m->ev0));
   HIP_OK(hipEventCreate(&m->ev1));
-  if (const char* a = getenv("SMATRIX_GROW_FORK")) m->grow_fork = *a != '0';
   if (m->grow_fork) {
     HIP_OK(hipStreamCreateWithFlags(&m->helper, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -2448,39 +2476,28 @@ smatrix_t* smatrix_open(const char* fname) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
-  if (const char* a = getenv("SMATRIX_GET_SPLIT")) m->get_split = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_PLACE")) m->far_place = *a != '0';
   if (const char* a = getenv("SMATRIX_PEND")) m->pend_on = *a != '0';
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_far_place<512, FAR_PLACE_SMALL_LG + 1, REST_LDS_MAX_LG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)far_place_lds_bytes(REST_LDS_MAX_LG)));
   if (const char* a = getenv("SMATRIX_REST_SLICE")) m->rest_slice_cells = std::max<uint32_t>(64, (uint32_t)strtoul(a, nullptr, 10));
-  if (const char* a = getenv("SMATRIX_REST_GRID")) m->rest_grid = std::max<uint32_t>(1, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_FAR_JOIN")) m->far_join = *a != '0';
-  if (const char* a = getenv("SMATRIX_FAR_LANES")) m->far_lanes = *a == '1';
-  if (const char* a = getenv("SMATRIX_ABSENT_SPLIT")) m->absent_split = *a != '0';
-  if (const char* a = getenv("SMATRIX_RETRY_SPLIT")) m->retry_split = *a != '0';
-  if (const char* a = getenv("SMATRIX_SMALL_FIRST")) m->small_first = *a != '0';
-  if (const char* a = getenv("SMATRIX_RETRY_FAR")) m->retry_far = *a != '0';
-  if (const char* a = getenv("SMATRIX_COLD_FAR")) m->cold_far = *a != '0';
-  if (const char* a = getenv("SMATRIX_COLD_ALL_FAR")) m->cold_all_far = *a != '0';
-  if (const char* a = getenv("SMATRIX_COLD_FAR_MAX")) m->cold_far_max = (uint32_t)strtoul(a, nullptr, 10);
-  if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters of k_grow_rest_lds from this batch on)
+#ifdef SMX_MEASURE    /* measurement builds only (make HIPCC="hipcc -DSMX_MEASURE"): the event counters of the dense-id kernels, printed at close */
+  if (const char* a = getenv("SMATRIX_REST_DBG_FROM")) m->rest_dbg_from = strtoull(a, nullptr, 10);     // (counters from this batch on)
   if (const char* a = getenv("SMATRIX_REST_DBG")) {
     m->rest_dbg_mode = (uint32_t)strtoul(a, nullptr, 10);
     dev_malloc(&m->rest_dbg, 1024);
     HIP_OK(hipMemset(m->rest_dbg, 0, 1024));
     HIP_OK(hipMemcpy(m->arena.base + offsetof(ArenaHead, dbg), &m->rest_dbg, 8, hipMemcpyHostToDevice));
   }
-  if (const char* a = getenv("SMATRIX_AGG_MIN")) m->agg_min = (uint32_t)strtoul(a, nullptr, 10);
-  if (const char* a = getenv("SMATRIX_AGG_MIN_RETRY")) m->agg_min_retry = (uint32_t)strtoul(a, nullptr, 10);
-  m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* a = getenv("SMATRIX_DBG_AFTER")) m->dbg_after = strtoull(a, nullptr, 10);
+#endif
+  m->io_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char* a = getenv("SMATRIX_BULK")) m->bulk_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_SPEC")) m->spec_enabled = *a != '0';
   if (const char* a = getenv("SMATRIX_COLD_MIN")) m->cold_min = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_COLD_SHARE")) m->cold_share = std::max(1u, (uint32_t)strtoul(a, nullptr, 10));
   if (const char* a = getenv("SMATRIX_CLUSTERED")) { m->clustered = *a != '0'; m->clustered_forced = true; }
-  if (const char* a = getenv("SMATRIX_WPO_MAX")) m->wpo_max = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_HINT_LG")) m->hint_lg = std::min(28u, (uint32_t)strtoul(a, nullptr, 10));
   clustered_sync(m, m->stream);
   if (const char* a = getenv("SMATRIX_SPEC_TINY")) m->spec_tiny = *a == '1';
@@ -2490,12 +2507,10 @@ smatrix_t* smatrix_open(const char* fname) {
   if (const char* a = getenv("SMATRIX_COMPACT_AT_CLOSE")) m->compact_at_close = *a == '1' && getenv("SMATRIX_EXPERIMENTAL") && *getenv("SMATRIX_EXPERIMENTAL") == '1';
   if (const char* a = getenv("SMATRIX_FLUSH_EVERY")) m->flush_every = strtoull(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_FLUSH_MS")) m->flush_ms = strtoull(a, nullptr, 10);
-  if (const char* a = getenv("SMATRIX_PREP_BLOCKS")) m->prep_blocks = (uint32_t)strtoul(a, nullptr, 10);
   if (const char* a = getenv("SMATRIX_IO_WINDOW_MB")) m->io_window = std::max<uint64_t>(1, strtoull(a, nullptr, 10)) << 20;
   if (const char* a = getenv("SMATRIX_IO_THREADS")) m->io_threads = std::max(1u, (unsigned)strtoul(a, nullptr, 10));
-  if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) { m->trace_rounds = *t == '1' || *t == '2'; m->trace_sync = *t == '2'; }
-  const char* prof = getenv("SMATRIX_PROFILE");
-  m->profile = prof && *prof == '1';
+  if (const char* t = getenv("SMATRIX_TRACE_ROUNDS")) { m->trace_rounds = *t == '1' || *t == '2' || *t == '3'; m->trace_sync = *t == '2'; }
+  m->profile = false;                   // (smatrix_profile() switches the kernel timers on)
 
   if (fname) {
     m->fname = fname;
@@ -2759,7 +2774,7 @@ void launch_getrow(Matrix* m, hipStream_t s, uint32_t n, const uint32_t* x, cons
   m->big.need((size_t)n + 1);
   HIP_OK(hipMemsetAsync(m->big.p, 0, 4, s));
   uint32_t grid = std::min<uint32_t>(blocks_for((uint64_t)n * 64), 16384);
-  static const int variant = getenv("SMATRIX_GETROW_VARIANT") ? atoi(getenv("SMATRIX_GETROW_VARIANT")) : 0;   // (tools/probe/getrow_variants.py)
+  constexpr int variant = 0;          // (the variants of profiles/r03_getrow_variants.txt were measured with a switch here; 0 is what ships)
 #define GR(A, X, D) hipLaunchKernelGGL((k_getrow<A, X, D>), dim3(grid), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, n, x, off, ret, counts, m->big.p)
   switch (variant) {
     case 1: GR(1, false, 0); break;      // round 2's shape: one step ahead, workgroups as numbered

@@ -231,7 +231,7 @@ class ShardedMatrix:
         self.shard = shard if shard is not None else HipShard()
         self.part = partitioner if partitioner is not None else HipPartitioner(device)
         self.exchanged_ops = 0
-        self.packed = os.environ.get("SMATRIX_SHARD_PACKED", "1") != "0"   # one collective per op batch
+        self.packed = True                                                # one collective per op batch (three collectives: slower, its switch is gone)
         self.host_staged = os.environ.get("SMATRIX_SHARD_HOST_STAGED", "0") == "1"
         self.auto_place = auto_place and os.environ.get("SMATRIX_SHARD_PLACE", "1") != "0"
         self.hot_rows = hot_rows

@@ -104,3 +104,12 @@ def test_router_binds_the_rccl_the_process_already_holds():
     if torch_copy:
         assert "/torch/lib/" in tpath, (tpath, path)           # torch's copy, not a second one
     assert int(tn_mapped) == 1, "two RCCL copies mapped in one process"
+    # SMATRIX_RCCL_LIB: a process that holds no RCCL yet loads the copy the variable names (here torch's, without importing torch)
+    if torch_copy:
+        tl = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+        cand = sorted(f for f in os.listdir(tl) if f.startswith("librccl.so"))
+        named = subprocess.run([sys.executable, "-c", code % ("", so)], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, SMATRIX_RCCL_LIB=os.path.join(tl, cand[0])))
+        assert named.returncode == 0, named.stderr[-2000:]
+        npath, nversion, nn = named.stdout.split()
+        assert "/torch/lib/" in npath and int(nn) == 1, (npath, path)

@@ -32,12 +32,16 @@ SOAK_ENVS = {
                              "SMATRIX_SCRATCH_POOL": "0", "SMATRIX_FLUSH_SNAPSHOT_MB": "1"},
     # clustered mode decided by the data, default hint table, the far join and the in-LDS move of clustered rows as shipped
     "defaults": {},
+    # (round 6) clustered mode from the start, the doubling rows' displaced cells in slices of 64 (a hundred workgroups per big row),
+    # tiny chain estimates on top (refused growth tasks leave their waiting keys to the retry)
+    "clustered-slices-tiny-chain": {"SMATRIX_CLUSTERED": "1", "SMATRIX_REST_SLICE": "64", "SMATRIX_SPEC_TINY": "1"},
 }
 
 
 @pytest.mark.parametrize("name", list(SOAK_ENVS))
 def test_bounded_soak(G, oracle_mod, monkeypatch, name):
-    """tests/soak.py's generator against the oracle, 36 batches of up to 3 x 10^5 ops per seed (Zipf, uniform, dense ids, dense
+    """(round 6: 80 batches per seed, four environments: the hand-run sets of round 5 moved under the driver's eyes)
+    tests/soak.py's generator against the oracle, batches of up to 3 x 10^5 ops per seed (Zipf, uniform, dense ids, dense
     Zipf ranks on a handful of rows; incr / decr / set / get, with and without result arrays; scalar calls on mirrored cells;
     flushes; close and reopen in the middle with both loaders reading both files) under the forced-path switches of the write
     path.  Per-key return multisets, post-batch gets, and every ten batches row sizes / used counters / cell contents / the
@@ -47,9 +51,9 @@ def test_bounded_soak(G, oracle_mod, monkeypatch, name):
         monkeypatch.setenv(k, v)
     from tests import soak
     t0 = time.time()
-    st = soak.run(nb=36, seed={"tiny-chain-bulk-flush": 11, "clustered-hints-cold": 12, "defaults": 13}[name],
+    st = soak.run(nb=80, seed={"tiny-chain-bulk-flush": 11, "clustered-hints-cold": 12, "defaults": 13, "clustered-slices-tiny-chain": 14}[name],
                   sizes=(1, 7, 300, 5000, 60000, 300000), episode=name == "clustered-hints-cold", sample_rows=120, verbose=False)
-    assert time.time() - t0 < 120, "the bounded soak must stay bounded"
+    assert time.time() - t0 < 240, "the bounded soak must stay bounded"
     assert st["batches"] >= 20 and st["rows"] > 1000, st
     if name == "clustered-hints-cold":
         assert st["clustered_mode"] == 1
@@ -237,15 +241,13 @@ def test_dense_zipf_stream_with_and_without_the_far_join(G, oracle_mod, monkeypa
 
 
 # ---- the cold rounds of a dense-id batch: keys below their row's size first, then free home cells, then the walks --------------------
-@pytest.mark.parametrize("small_first", ["1", "0"])
-def test_cold_start_of_dense_ids_takes_small_keys_first(G, oracle_mod, monkeypatch, small_first):
+def test_cold_start_of_dense_ids_takes_small_keys_first(G, oracle_mod, monkeypatch, small_first="1"):
     """A first batch of 2^21 dense Zipf ranks on 48 rows (and a second one on top): the deferred list goes through the cold start
     (one key per distinct pair, k_dedup_keys, whose count of keys below the list's length tells dense ids from hashed ones) and its
     rounds run three launches of k_insert_keys each -- keys below their row's size at a free home cell, any key at a free home
-    cell, the walks -- or, with SMATRIX_SMALL_FIRST=0, one launch in list order.  Whatever the order, the batch is SOME
-    serialisation of its ops: row sizes and used counters are the oracle's exactly, the cells are the oracle's as a set, and no
-    probe sequence has an empty cell inside."""
-    monkeypatch.setenv("SMATRIX_SMALL_FIRST", small_first)
+    cell, the walks (round 6: the list-order variant behind SMATRIX_SMALL_FIRST=0 is gone with its switch).  Whatever the order,
+    the batch is SOME serialisation of its ops: row sizes and used counters are the oracle's exactly, the cells are the oracle's
+    as a set, and no probe sequence has an empty cell inside."""
     monkeypatch.setenv("SMATRIX_COLD_MIN", "4096")
     from libsmatrix_amd import Stream
     gen = Stream("zipf", 4242, 1000000, 1.1, 0)
@@ -283,9 +285,10 @@ def test_cold_start_of_dense_ids_takes_small_keys_first(G, oracle_mod, monkeypat
     g.close(); o.close(); gen.close()
 
 
-@pytest.mark.parametrize("seed,configs", [(5, 10), (12, 14)])
+@pytest.mark.parametrize("seed,configs", [(5, 10), (12, 14), (41, 25), (42, 25), (43, 25), (44, 25), (45, 25), (46, 25)])
 def test_cold_start_soak_bounded(G, oracle_mod, monkeypatch, seed, configs):
-    """tests/cold_soak.py, ten configurations of one seed: 4..300 rows, two or three batches of 2^16..2^21 incr / decr ops of Zipf ranks
+    """(round 6: the six seeds x 25 configurations that profiles/r05_soak_runs.txt ran by hand are under the driver's eyes now)
+    tests/cold_soak.py, ten to twenty-five configurations of one seed: 4..300 rows, two or three batches of 2^16..2^21 incr / decr ops of Zipf ranks
     (plain, shifted by a random base, or mixed with hashed ids), later batches on top of the first one's tables -- the cold rounds in
     their three launches, the walkers through the far join.  Returns, gets, sizes, used counters, cells and the probe invariant
     are the oracle's."""
@@ -293,7 +296,7 @@ def test_cold_start_soak_bounded(G, oracle_mod, monkeypatch, seed, configs):
     from tests import cold_soak
     t0 = time.time()
     cold_soak.run(configs, seed)      # (seed 12, configuration 13: a row that ends a batch at exactly size/2 + 1 keys, one of them named by two
-    assert time.time() - t0 < 90      #  ops of the pass in front of prep -- prep's probe by the LIVE occupancy words stepped over the claimed cell and doubled the row)
+    assert time.time() - t0 < 150     #  ops of the pass in front of prep -- prep's probe by the LIVE occupancy words stepped over the claimed cell and doubled the row)
 
 
 # ---- the host-pointer batch API as a three-stage pipeline ------------------------------------------------------
