@@ -104,6 +104,9 @@ def short_line(full, detail_path=None):
             "matches_reference_checksums": g(full, "reference_checksums", "matches_reference"),
             "dense_ids_Mops_per_s": g(full, "dense_ids", "Mops_per_s"),
             "dense_ids_first_step_ms": g(full, "dense_ids", "first_step_ms"),
+            # (the incr call of the first step / of a mean late step: wall, waiting for the device, device allocations, the rest)
+            "dense_ids_first_step_split": g(full, "dense_ids", "first_step_incr_split"),
+            "dense_ids_mean_step_split": g(full, "dense_ids", "mean_step_incr_split"),
             "dense_ids_matches_reference": g(full, "dense_ids", "matches_reference"),
             "roofline_dense": _pick(g(full, "dense_ids", "roofline_dense") or {}, "kernel", "avg_launch_ms", "traffic", "r04_fetch_bytes", "achieved", "frac"),
             "op_kinds_Gops_per_s": g(full, "op_kinds", "Gops_per_s"),
@@ -845,6 +848,7 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
     from libsmatrix_amd import SparseMatrix, Stream, OP_GET, OP_INCR
     gen = Stream("zipf", SEED, N_IDS, ZIPF_S, 0)
     m = SparseMatrix()
+    m.reserve(8 << 30)                  # (the capacity hint of include/smatrix_batch.h: the row arena's first 8 GB are mapped before the clock starts)
     xs = torch.empty((steps, B), dtype=torch.int32, device=dev); ys = torch.empty_like(xs)
     for k in range(steps):
         gen.fill_device(k * B, B, xs[k].data_ptr(), ys[k].data_ptr(), stream)
@@ -853,9 +857,15 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
     warm = 2
     m.profile(True)
     first_ms = None
+    # where a write batch's wall time goes (smatrix_stats_t::write_*_ms, round 6): waiting for the device in the read-backs between
+    # rounds (kernels running), device allocations / frees / maps, and the rest -- host work between launches
+    split = lambda s: {"call_ms": s["last_write_call_ms"], "device_wait_ms": s["last_write_wait_ms"], "alloc_ms": s["last_write_alloc_ms"],
+                       "host_ms": s["last_write_call_ms"] - s["last_write_wait_ms"] - s["last_write_alloc_ms"]}
+    first_split = None
     for k in range(steps):
         if k == warm:
             m.profile(True)
+            st_w = m.stats()
             torch.cuda.synchronize(); t0 = time.perf_counter()
         if k == 0:
             torch.cuda.synchronize(); tf = time.perf_counter()
@@ -863,9 +873,14 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
         m.apply_batch_dev(OP_GET, B, xs[k].data_ptr(), ys[k].data_ptr(), None, o2.data_ptr(), stream)
         if k == 0:
             torch.cuda.synchronize(); first_ms = (time.perf_counter() - tf) * 1e3      # (the cold start of a dense-id matrix: every row created, the keys of the hot rows in their best order)
+            first_split = split(m.stats())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = m.stats()
+    nn = max(steps - warm, 1)
+    late_split = {"call_ms": (st["write_call_ms"] - st_w["write_call_ms"]) / nn, "device_wait_ms": (st["write_wait_ms"] - st_w["write_wait_ms"]) / nn,
+                  "alloc_ms": (st["write_alloc_ms"] - st_w["write_alloc_ms"]) / nn}
+    late_split["host_ms"] = late_split["call_ms"] - late_split["device_wait_ms"] - late_split["alloc_ms"]
     ok = bool((o2 >= 1).all().item()) and int(st["rows"]) <= N_IDS
     m.close()
     # Parity at full size, untimed: relabelling the ids does not change what the stream builds, so a second matrix fed exactly
@@ -907,6 +922,7 @@ def dense_ids_leg(torch, dev, B, stream, steps=24):
     except Exception:
         rd = None
     return {"steps": n, "ms_per_step": dt / n * 1e3, "Mops_per_s": 2 * B * n / dt / 1e6, "first_step_ms": first_ms, "rows": int(st["rows"]), "roofline_dense": rd,
+            "first_step_incr_split": first_split, "mean_step_incr_split": late_split,
             "incr_kernel_ms": st["kernel_ms_incr"] / max(st["kernel_launches_incr"], 1),
             "get_kernel_ms": st["kernel_ms_get"] / max(st["kernel_launches_get"], 1), "sanity": ok,
             "at_4e8_ops": got, "matches_reference": None if got is None else all(got[k] == ref[k] for k in ref),

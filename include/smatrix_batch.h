@@ -180,13 +180,14 @@ void smatrix_stats_sz(smatrix_t* self, smatrix_stats_t* out, size_t size);
  * time; a larger backlog goes out in several such steps); the copies to the host and the writes run without it, as the
  * reference's IO thread writes under per-row read locks only (:929-960): callers on other threads keep their latency
  * (measured: a 1 GB flush, batch gets p99 23 -> 25 us).  A row that changes while a flush writes goes out with the next.
- * SMATRIX_FLUSH_EVERY=N flushes after every N-th write batch (inside that call), SMATRIX_FSYNC=1 adds fsync() after the
- * row blocks and after the entries.  Memory mode: no-op.  Returns 0.
- * Lock order: matrix lock, then the file lock, and a flush keeps the file lock while it writes.  smatrix_flush waits for a
- * flush in flight WITHOUT the matrix lock; a SMATRIX_FLUSH_EVERY checkpoint and smatrix_close wait for it while they hold the
- * matrix lock (they are inside a call that owns it), so callers on other threads wait for the rest of that write -- at most one
- * snapshot, 2 GB, a few tenths of a second.  Where that matters run checkpoints OR the background flusher
- * (SMATRIX_FLUSH_MS=0 turns it off), not both. */
+ * SMATRIX_FLUSH_EVERY=N checkpoints after every N-th write batch (by the call that made it, once it has released the matrix
+ * lock; a host-pointer call that runs in chunks is ONE batch), SMATRIX_FSYNC=1 adds fsync() after the row blocks and after the
+ * entries.  Memory mode: no-op.  Returns 0.
+ * Lock order (round 6): the FILE lock first, then the matrix lock, everywhere -- smatrix_flush, the background flusher, a
+ * SMATRIX_FLUSH_EVERY checkpoint, smatrix_compact, smatrix_close.  A flush keeps the file lock while it writes and holds the
+ * matrix lock only for its snapshot; whoever wants the file next queues for it WITHOUT the matrix lock, so no caller of the
+ * handle ever stands behind a thread that waits for a write in flight
+ * (tests/test_gpu_round6.py::test_a_second_flush_does_not_hold_up_the_callers). */
 int smatrix_flush(smatrix_t* self);
 /* EXPERIMENTAL, no reference counterpart (the reference's files only grow: resized rows leave their old block behind,
  * src/smatrix.c:430-436, and so do this library's -- same format, same leak): rewrites the backing file without those

@@ -664,7 +664,8 @@ static_assert(((size_t)1 << (REST_LDS_MAX_LG - 3)) + ((size_t)1 << (REST_LDS_MAX
 //   k_grow_rest_plan (one workgroup) deals out slices: ceil(n_disp / REST_SLICE_CELLS) per row, at most REST_MAX_SLICES, the
 //     rows with the most slices first, and marks the rows it took (bit 31 of n_disp: k_grow_move_rest leaves those alone);
 //   k_grow_rest_lds: a workgroup per slice.  The slice's range of old chunks is cut by the displaced counts (cell-balanced).
-constexpr uint32_t REST_SLICE_CELLS = 512;               // displaced cells a slice places in order (8 steps of one wave when they are one piece)
+constexpr uint32_t REST_SLICE_CELLS = 1024;              // displaced cells a slice places in order (16 steps of one wave when they are one piece; swept 256 / 512 /
+                                                         // 1024 / 2048 / 4096 on the dense-id stream: 5.20 / 5.08 / 5.01 / 5.03 / 5.26 ms per step)
 constexpr uint32_t REST_MAX_SLICES = 64;
 // GrowTask::n_disp: a wave per 64 old chunks adds up their masks' bits, one atomic per wave and row
 __global__ __launch_bounds__(256) void k_grow_rest_count(const Ctl* ctl, GrowTask* tasks, const uint32_t* map_old, const unsigned long long* disp) {

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_dense_* (tools/refresh_dense_profile.sh) into profiles/r05_dense_kernels.txt and profiles/pmc_dense.json."""
+"""Turns gpurun_out/prof_dense_* (tools/refresh_dense_profile.sh) into profiles/r06_dense_kernels.txt and profiles/pmc_dense.json."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools.build_profiles_common import kernel_source_sha16
-RND = "r05"
+RND = "r06"
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 rd = lambda n: open(os.path.join(G, n)).read()
 run = rd("prof_dense_run.txt").strip().splitlines()

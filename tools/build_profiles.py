@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Turns the raw outputs of tools/refresh_profiles.sh (gpurun_out/prof_*) into the files committed under profiles/:
-r05_bench.json (the full result; the stdout line is its short form), r05_rocprof_kernel_stats.txt, r05_pmc_summary.txt, pmc.json
-(keyed to the kernel source hash), r05_getrow_config3.txt, r05_floor.txt."""
+r06_bench.json (the full result; the stdout line is its short form), r06_rocprof_kernel_stats.txt, r06_pmc_summary.txt, pmc.json
+(keyed to the kernel source hash), r06_getrow_config3.txt, r06_floor.txt."""
 import hashlib, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = "r05"
+RND = "r06"
 
 
 def kernel_source_sha16():
@@ -38,7 +38,7 @@ rd_agg = agg["miss"] - agg["atom"]
 t_agg = rd_agg / (R * 1e9) + agg["atom"] / (A * 1e9); t_get = get["miss"] / (R * 1e9)
 ki, kg = b["roofline"]["avg_launch_ms"], b["roofline_get"]["avg_launch_ms"]
 hdr = """# rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 bench.py --no-cpu --no-extras   (three separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum; tools/refresh_profiles.sh + tools/build_profiles.py)
-# MI355X, round 5, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
+# MI355X, round 6, bench.py --no-cpu --no-extras: config 2 = 24 batches of 2^24 ops (+ 4 replayed batches of the steady-state extra).  FETCH_SIZE/WRITE_SIZE are KiB per dispatch, means over the dispatches listed.
 # Calibration in our own access pattern, same runs: k_probe_random<0> = 2^27 random 8-byte loads over 4 GiB -> %.0f KiB = %.1f B per touch
 #   (a 64 B line per touch; no 1/2 correction for this shape); k_probe_random<1>/<2> = 2^27 scattered 32-bit atomics -> WRITE_SIZE 32 B and TCC_EA0_ATOMIC 1.0 per atomic.
 #   (the guide's gfx950 correction -- FETCH_SIZE tallies a 128-B coalesced streaming request at 64 B -- applies only to the streamed op arrays,
@@ -70,7 +70,7 @@ json.dump({"summary": "profiles/%s_pmc_summary.txt" % RND, "kernel_source_sha16"
                            "l2_misses": get["miss"]}}, open(os.path.join(P, "pmc.json"), "w"), indent=1)
 ur = json.load(open(os.path.join(G, "prof_bench_under_rocprof.json")))
 open(os.path.join(P, RND + "_rocprof_kernel_stats.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 5, tools/refresh_profiles.sh; bench line of this "
+    "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu --no-extras   (MI355X, round 6, tools/refresh_profiles.sh; bench line of this "
     "same profiled run: %.0f Mops/s, k_apply_agg<INCR> round-0 avg %.3f ms and k_apply<GET> %.3f ms by HIP events; the full-batch grids below include the 4 all-hit "
     "replays of the steady-state extra and the first batches of the empty table)\n" % (ur["value"], ur["roofline"]["avg_launch_ms"], ur["roofline_get"]["avg_launch_ms"])
     + open(os.path.join(G, "prof_kernel_stats.txt")).read()
@@ -98,7 +98,7 @@ def val3(kern, ctr):
 
 f3, w3 = val3("smx::k_getrow", "FETCH_SIZE"), val3("smx::k_getrow", "WRITE_SIZE")
 d3 = c3["result"]
-lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 5" % (d3["rows"], d3["nnz"]),
+lines = ["# config 3 (bench.py --config 3): smatrix_rowlen + smatrix_getrow over all %d rows / %d nnz of the CF matrix, MI355X, round 6" % (d3["rows"], d3["nnz"]),
          "# bench line of the profiled run: getrow %.3f ms = %.1f G nnz/s; algorithmic %.0f GB/s = %.3f of the 8 TB/s peak; build %.2f s (%.2f G ops/s)"
          % (d3["getrow_ms"], d3["Gnnz_per_s"], d3["roofline"]["achieved"], d3["roofline"]["frac"], d3["build_s"], d3["build_Gops_per_s"])]
 if f3 and w3:
@@ -135,7 +135,7 @@ ins = agg["atom"] - 15.0e6                                           # tickets +
 floor_agg = t_agg * 1e3
 floor_get = t_get * 1e3
 lines_f = [
- "# The floor of one mixed step (incr batch + get batch of 2^24 ops each, config 2) of THIS design on THIS box -- round 5 (the kernels of the headline path are those of round 4: frozen).",
+ "# The floor of one mixed step (incr batch + get batch of 2^24 ops each, config 2) of THIS design on THIS box -- round 6 (the kernels of the headline path are those of round 4: frozen).",
  "# Every count is a PMC mean of the committed passes (profiles/%s_pmc_summary.txt), every rate a probe of the same bench run" % RND,
  "# (random_access in profiles/%s_bench.json); nothing here is estimated from prose." % RND,
  "",
