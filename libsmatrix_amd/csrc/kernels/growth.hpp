@@ -283,9 +283,11 @@ struct WaveScope {                                   // the lanes of one wave; L
   }
 };
 //   l_old : 2^old_lg cells, l_tab : 2^(old_lg+1) slot indices, l_cd : {count, dup}, all private to the scope
+__device__ inline uint32_t rest_enter(unsigned long long* B, unsigned long long* S, uint32_t nw, uint32_t nmask, bool valid, uint32_t home);   // (below)
+// l_bits (round 6): room for one bit per new slot + one per 64-bit word of those, for the waiting keys of big tables
 template <typename S>
 __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, uint64_t* l_old, uint32_t* l_tab,
-                                              uint32_t* l_cd, const uint32_t* pend_keys = nullptr) {
+                                              uint32_t* l_cd, const uint32_t* pend_keys = nullptr, unsigned long long* l_bits = nullptr) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
   const uint32_t tid = S::tid();
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
@@ -322,6 +324,31 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
     S::sync();                                       // (everybody has read the count)
     if (take) {
       pend = pend_keys + task->pend_off;
+      const uint32_t nw = new_size >> 6;
+      if (l_bits && nw >= 64 && S::T >= 64) {
+        // tables of >= 4096 new cells: on a BITMAP of the slots the old cells took, like the cells in front of a slice
+        // (rest_enter).  By priority probing the waiting keys of one run evict each other one cell at a time down the whole
+        // run: 0.36 ms for the 8192-cell rows of a late dense-id batch, as long as the chunked passes beside them.
+        unsigned long long* Bm = l_bits;
+        unsigned long long* Sm = l_bits + nw;
+        for (uint32_t q = tid; q < new_size; q += S::T) {
+          const uint64_t m = __ballot(l_tab[q] != NONE);
+          if ((q & 63u) == 0) Bm[q >> 6] = m;
+        }
+        S::sync();
+        for (uint32_t sw = tid; sw < (nw >> 6); sw += S::T) {
+          unsigned long long m = 0;
+          for (uint32_t b = 0; b < 64; b++) if (Bm[sw * 64 + b] == ~0ull) m |= 1ull << b;
+          Sm[sw] = m;
+        }
+        S::sync();
+        for (uint32_t i0 = tid & ~63u; i0 < take; i0 += S::T) {             // (wave-uniform)
+          const uint32_t i = i0 + (tid & 63u);
+          const bool valid = i < take;
+          const uint32_t z = rest_enter(Bm, Sm, nw, nmask, valid, valid ? pend[i] & nmask : 0u);
+          if (valid && z <= nmask) l_tab[z] = old_size + i;
+        }
+      } else
       for (uint32_t i = tid; i < take; i += S::T) {
         uint32_t cur = old_size + i, q = pend[i] & nmask;
         for (;;) {
@@ -361,7 +388,9 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
       const uint32_t r = l_tab[q];
       const uint64_t c = r == NONE ? 0ull : r >= old_size ? pack_cell(pend[r - old_size], 0u) : l_old[r];
       T[q] = c;
-      if (r != NONE && home_on && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);   // (beyond the lane's budget: remembered -- the old table's hints died with its block)
+      // (a waiting key that landed beyond a lane's budget is remembered: the retry asks the hint table.  Re-hinting the OLD cells
+      //  that move far as well was measured -- the old table's hints die with its block -- and bought nothing: 0.31 vs 0.18 ms here)
+      if (r != NONE && r >= old_size && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);
       if (bits) {
         const uint64_t hm = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & nmask) == q);
         if ((q & 63u) == 0) hb[q >> 6] = hm;
@@ -378,16 +407,18 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
   S::sync();
 }
 
+__host__ __device__ inline size_t grow_lds_bytes(uint32_t max_lg) { return ((size_t)16 << max_lg) + ((size_t)2 << max_lg) / 8 + 64; }
 // one workgroup (THREADS = 64: one wave) per task of the given kind
 template <int THREADS, uint32_t MAX_LG>
 __global__ __launch_bounds__(THREADS) void k_grow_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
                                                       uint32_t kind, uint8_t* arena, const uint32_t* pend_keys) {
   extern __shared__ uint64_t l_dyn[];                               // 2^MAX_LG cells ...
   uint32_t* l_tab = reinterpret_cast<uint32_t*>(l_dyn + (1u << MAX_LG));   // ... and 2^(MAX_LG+1) slot indices
+  unsigned long long* l_bits = reinterpret_cast<unsigned long long*>(l_tab + (2u << MAX_LG));   // ... and a bit per new slot (+ summary): grow_lds_bytes
   __shared__ uint32_t l_cd[2];
   const uint32_t n = ctl->n_kind[kind];
   for (uint32_t li = blockIdx.x; li < n; li += gridDim.x)                     // block-uniform
-    grow_lds_task<BlockScope<THREADS>>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd, pend_keys);
+    grow_lds_task<BlockScope<THREADS>>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd, pend_keys, l_bits);
 }
 
 // one wave per 64 old slots
@@ -970,9 +1001,6 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
           const unsigned long long before = atomicOr(&B[z >> 6], bit);
           if ((before | bit) == ~0ull) atomicOr(&S[z >> 12], 1ull << ((z >> 6) & 63u));
           T[z] = cell;
-          // (a cell that ends beyond a lane's budget: the hints of the old table died with its block -- the first op that names the
-          //  key would walk with its wave again, the get behind this batch included; hint_put does nothing without a hint table)
-          if (((z - cell_key(cell)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(cell), z);
           pending = false;
         }
         if (pending) cur = t;                                               // (everything below t is taken: the next look starts there)
@@ -1089,6 +1117,8 @@ __global__ __launch_bounds__(256) void k_far_absent(const DirSlot* dir, const ui
                                                     uint32_t cap_units, uint32_t* bucket, uint32_t* rows, uint32_t rows_cap) {
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
   if (ah->twins || ah->far_overflow) return;                               // (uniform: the pass does not use the join then / takes no claimed inserts)
+  // (a list of the entries k_far_keys creates instead of this pass over the table was measured: this kernel 64 -> 28 us, k_far_keys
+  //  52 -> 98 -- one returning atomic per wave on the list's one counter)
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e <= tmask; e += gridDim.x * blockDim.x) {
     const uint4 v = tab[e];
     if (v.x == 0 || v.z != FAR_NOT_FOUND) continue;                         // (unused, a row's own entry, or a key the scan has found)
@@ -1122,7 +1152,16 @@ __global__ __launch_bounds__(FAR_PLACE_THREADS) void k_far_place(DirSlot* dir, c
     const uint32_t n = min(rcnt[fu], units * FAR_BUCKET_PER_UNIT);         // (what the bucket holds)
     uint64_t* cells = row_cells(arena, d.base);
     __syncthreads();                                                        // (the previous row's bitmap is done with)
-    for (uint32_t w = threadIdx.x; w < nw; w += FAR_PLACE_THREADS) B[w] = occ0[(size_t)fu * FAR_UNIT_WORDS + w];
+    {                                                                      // (four words per lane in flight: a 2^20-cell row's 16 384 words one load after the other were 30 us)
+      const unsigned long long* src = occ0 + (size_t)fu * FAR_UNIT_WORDS;
+      for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 4u * FAR_PLACE_THREADS) {
+        unsigned long long q[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) q[j] = w0 + j * FAR_PLACE_THREADS < nw ? src[w0 + j * FAR_PLACE_THREADS] : 0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) if (w0 + j * FAR_PLACE_THREADS < nw) B[w0 + j * FAR_PLACE_THREADS] = q[j];
+      }
+    }
     __syncthreads();
     for (uint32_t sw = threadIdx.x; sw < (nw >> 6); sw += FAR_PLACE_THREADS) {
       unsigned long long m = 0;

@@ -195,13 +195,15 @@ __device__ inline uint4* far_entry(uint4* tab, uint32_t tmask, uint32_t base, ui
   return nullptr;
 }
 // insert {base, Y} (slot not known yet); false when the table is too crowded around its home
-__device__ inline bool far_insert(uint4* tab, uint32_t tmask, uint32_t base, uint32_t Y, uint32_t slot) {
+__device__ inline bool far_insert(uint4* tab, uint32_t tmask, uint32_t base, uint32_t Y, uint32_t slot, uint32_t* created_at = nullptr) {
+  // created_at: the entry's index when THIS call created it, else 2^32-1
   const unsigned long long key = ((unsigned long long)base << 32) | Y;
   uint32_t e = far_hash(base, Y) & tmask;
+  if (created_at) *created_at = 0xFFFFFFFFu;
   for (uint32_t guard = 0; guard < 64; guard++) {
     unsigned long long prev = *reinterpret_cast<const unsigned long long*>(&tab[e]);
     if (prev == 0ull) prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[e]), 0ull, key);
-    if (prev == 0ull || prev == key) { if (prev == 0ull || slot != FAR_NOT_FOUND) tab[e].z = slot; return true; }
+    if (prev == 0ull || prev == key) { if (prev == 0ull || slot != FAR_NOT_FOUND) tab[e].z = slot; if (prev == 0ull && created_at) *created_at = e; return true; }
     e = (e + 1) & tmask;
   }
   return false;

@@ -1158,13 +1158,13 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   const bool fork = m->grow_fork && n_chunked && (nk[0] || nk[1] || nk[2]);
   if (fork) HIP_OK(hipEventRecord(m->ev_fork, s));
   if (nk[0])
-    hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), 16u << GROW_LG0, s,
+    hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), grow_lds_bytes(GROW_LG0), s,
                        m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base, pend_keys);
   if (nk[1])
-    hipLaunchKernelGGL((k_grow_lds<256, GROW_LG1>), dim3(std::min<uint32_t>(nk[1], 4096)), dim3(256), 16u << GROW_LG1, s,
+    hipLaunchKernelGGL((k_grow_lds<256, GROW_LG1>), dim3(std::min<uint32_t>(nk[1], 4096)), dim3(256), grow_lds_bytes(GROW_LG1), s,
                        m->d_ctl, m->tasks.p, m->klist.p + m->klist_cap, 1u, m->arena.base, pend_keys);
   if (nk[2])
-    hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), 16u << GROW_LG2, s,
+    hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), grow_lds_bytes(GROW_LG2), s,
                        m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base, pend_keys);
   DBG_STEP(m, s, "k_grow_lds x3");
   const uint64_t oc_bound = (uint64_t)n_chunked + gu / 8, nc_bound = (uint64_t)n_chunked + gu / 4;
@@ -2194,26 +2194,34 @@ struct HostPipe {
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[NB], ev_k[NB];
   CopyPool pool_in, pool_out;
+  bool ok = true;                        //  false: pinned or device memory for the three buffer sets was refused -- the call takes the single-copy path
   HostPipe(size_t chunk_ops, unsigned t_in, unsigned t_out) : chunk(chunk_ops) {
-    for (int b = 0; b < NB; b++) {
-      HIP_OK(hipHostMalloc(&h_in[b], chunk * 12));
-      HIP_OK(hipHostMalloc(&h_out[b], chunk * 4));
-      dev_malloc(&d_in[b], chunk * 12);
-      dev_malloc(&d_out[b], chunk * 4);
-      HIP_OK(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&ev_k[b], hipEventDisableTiming));
+    for (int b = 0; b < NB; b++) { ev_in[b] = nullptr; ev_k[b] = nullptr; }
+    for (int b = 0; b < NB && ok; b++) {
+      ok = ok && hipHostMalloc(reinterpret_cast<void**>(&h_in[b]), chunk * 12) == hipSuccess;
+      ok = ok && hipHostMalloc(reinterpret_cast<void**>(&h_out[b]), chunk * 4) == hipSuccess;
+      ok = ok && hipMalloc(reinterpret_cast<void**>(&d_in[b]), chunk * 12) == hipSuccess;
+      ok = ok && hipMalloc(reinterpret_cast<void**>(&d_out[b]), chunk * 4) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&ev_k[b], hipEventDisableTiming) == hipSuccess;
     }
-    HIP_OK(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    ok = ok && hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return; }
     pool_in.start(t_in);
     pool_out.start(t_out);
   }
   ~HostPipe() {
     for (int b = 0; b < NB; b++) {
-      (void)hipHostFree(h_in[b]); (void)hipHostFree(h_out[b]); (void)hipFree(d_in[b]); (void)hipFree(d_out[b]);
-      (void)hipEventDestroy(ev_in[b]); (void)hipEventDestroy(ev_k[b]);
+      if (h_in[b]) (void)hipHostFree(h_in[b]);
+      if (h_out[b]) (void)hipHostFree(h_out[b]);
+      if (d_in[b]) (void)hipFree(d_in[b]);
+      if (d_out[b]) (void)hipFree(d_out[b]);
+      if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
+      if (ev_k[b]) (void)hipEventDestroy(ev_k[b]);
     }
-    (void)hipStreamDestroy(s_in); (void)hipStreamDestroy(s_out);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_out) (void)hipStreamDestroy(s_out);
   }
 };
 
@@ -2225,17 +2233,23 @@ size_t host_chunk_ops() {              // (read per call: tests set it per handl
 
 // n ops from up to three host arrays (in[q] == nullptr: not used), results (when `out`) to a host array; `compute` enqueues the
 // kernels of one chunk on the matrix's stream: compute(count, d_a0, d_a1, d_a2, d_out).  Caller holds m->mu.
-template <typename F>
-void host_pipeline(Matrix* m, size_t n, const uint32_t* const in[3], uint32_t* out, F compute) {
+// the matrix's pipeline for the chunk size in force, or false when its buffers cannot be had (the caller then copies the whole arrays)
+bool host_pipe_ready(Matrix* m) {
   if (m->host_pipe && static_cast<HostPipe*>(m->host_pipe)->chunk != host_chunk_ops()) {
     delete static_cast<HostPipe*>(m->host_pipe);
     m->host_pipe = nullptr;
   }
   if (!m->host_pipe) {
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-    m->host_pipe = new HostPipe(host_chunk_ops(), std::min(12u, hw / 2), std::min(8u, std::max(1u, hw / 4)));
+    HostPipe* hp = new HostPipe(host_chunk_ops(), std::min(12u, hw / 2), std::min(8u, std::max(1u, hw / 4)));
+    if (!hp->ok) { delete hp; return false; }
+    m->host_pipe = hp;
   }
-  HostPipe& hp = *static_cast<HostPipe*>(m->host_pipe);
+  return true;
+}
+template <typename F>
+void host_pipeline(Matrix* m, size_t n, const uint32_t* const in[3], uint32_t* out, F compute) {
+  HostPipe& hp = *static_cast<HostPipe*>(m->host_pipe);      // (host_pipe_ready(m) has been asked)
   const size_t C = hp.chunk, nc = (n + C - 1) / C;
   const int dev = m->device;
   std::mutex mu;
@@ -2473,7 +2487,7 @@ smatrix_t* smatrix_open(const char* fname) {
   HIP_OK(hipStreamSynchronize(m->stream));
   ctl_push_persistent(m, m->stream);
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 16 << GROW_LG2));
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)grow_lds_bytes(GROW_LG2)));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
   if (const char* a = getenv("SMATRIX_FAR_PLACE")) m->far_place = *a != '0';
@@ -2584,7 +2598,7 @@ void smatrix_close(smatrix_t* self) {
       if (m->h_row) (void)hipHostFree(m->h_row);
       m->row_ret.release();
       delete static_cast<HostPipe*>(m->host_pipe);
-      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release(); m->far_rcnt.release(); m->far_bucket.release(); m->far_prows.release(); m->far_bloom.release(); m->far_unit_info.release(); m->big_list.release();
+      m->far_tab.release(); m->far_unit_row.release(); m->far_zeros.release(); m->far_occ.release(); m->far_occ0.release(); m->far_clm.release(); m->far_rcnt.release(); m->far_bucket.release(); m->far_prows.release(); m->far_bloom.release(); m->far_unit_info.release(); m->big_list.release(); 
       m->pend_rec.release(); m->pend_keys.release(); m->task_of.release(); m->pend_ctl.release(); m->pend_hash.release();
       for (auto& d : m->defer) d.release();
       for (uint32_t c = 0; c < N_CLASSES; c++)
@@ -2663,7 +2677,7 @@ int smatrix_apply_batch(smatrix_t* self, int op, size_t n, const uint32_t* x, co
   std::lock_guard<std::mutex> g(m->mu);
   cache_sync(m, op != OP_GET);
   hipStream_t s = m->stream;
-  if (n >= 2 * host_chunk_ops() && (op == OP_GET || v)) {
+  if (n >= 2 * host_chunk_ops() && (op == OP_GET || v) && host_pipe_ready(m)) {
     // a large call: chunks through pinned memory, upload / kernels / return overlapped (host_pipeline)
     const uint32_t* in[3] = {x, y, op != OP_GET ? v : nullptr};
     m->no_ret = out == nullptr;
@@ -2730,7 +2744,7 @@ int smatrix_rowlen_batch(smatrix_t* self, size_t n, const uint32_t* x, uint32_t*
   set_device(m);
   std::lock_guard<std::mutex> g(m->mu);
   hipStream_t s = m->stream;
-  if (n >= 2 * host_chunk_ops()) {
+  if (n >= 2 * host_chunk_ops() && host_pipe_ready(m)) {
     const uint32_t* in[3] = {x, nullptr, nullptr};
     host_pipeline(m, n, in, out, [&](size_t cnt, uint32_t* dx, uint32_t*, uint32_t*, uint32_t* dout) {
       hipLaunchKernelGGL(k_rowlen, dim3(blocks_for(cnt)), dim3(256), 0, s, m->d_dir, m->dir_size - 1, m->arena.base, (uint32_t)cnt, dx, dout);
