@@ -199,7 +199,7 @@ int smatrix_flush(smatrix_t* self);
 int smatrix_compact(smatrix_t* self);
 #endif
 /* on: time every round-0 op kernel with HIP events on its stream (adds one sync per
- * batch); resets the kernel_* accumulators.  Also enabled by SMATRIX_PROFILE=1. */
+ * batch); resets the kernel_* accumulators. */
 void smatrix_profile(smatrix_t* self, int on);
 /* returns 1 if the row exists; size = slots, used = rowlen */
 int smatrix_row_info(smatrix_t* self, uint32_t x, uint32_t* size, uint32_t* used);

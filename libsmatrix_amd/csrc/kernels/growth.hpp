@@ -1059,15 +1059,16 @@ __global__ __launch_bounds__(REST_THREADS) void k_grow_rest_lds(const Ctl* ctl, 
       __syncthreads();
       const uint32_t take = cut[0];
       const uint32_t* pend = pend_keys + k.pend_off;
-      unsigned long long* hbn = row_home(arena, k.new_base, k.old_lg + 1);
+      // (a key that lands at home gets its bit in the at-home bitmap from k_grow_finish, not here: the workgroups of the row's
+      //  other slices may still be loading that bitmap -- they run in no particular order once a launch has more slices than
+      //  workgroups -- and must find the cells the FIRST pass stored, nothing else)
       for (uint32_t i0 = wave * 64u; i0 < take; i0 += REST_THREADS) {        // (wave-uniform)
         const bool valid = i0 + lane < take;
         const uint32_t key = valid ? pend[i0 + lane] : 0u;
         const uint32_t z = rest_enter(B, S, nw, nmask, valid, key & nmask);
         if (valid && z <= nmask) {
           T[z] = pack_cell(key, PEND_MARK);
-          if (z == (key & nmask)) atomicOr(&hbn[z >> 6], 1ull << (z & 63u));        // (at home: its bit in the at-home bitmap)
-          else if (((z - key) & nmask) > HINT_BUDGET) hint_put(arena, T, key, z);
+          if (((z - key) & nmask) > HINT_BUDGET) hint_put(arena, T, key, z);
         }
       }
       if (threadIdx.x == 0 && take) atomicAdd(&tasks[ti].count, take);
@@ -1235,8 +1236,12 @@ __device__ __forceinline__ void grow_finish_body(VGrid g, const Ctl* ctl, GrowTa
     if (q < new_size) {
       uint64_t* T = row_cells(arena, k.new_base);
       uint64_t c = T[q];
+      // a key that waited for this doubling: {key, 0}, and its bit in the at-home bitmap when it sits at home (one word per wave)
+      const bool waited = c != 0 && cell_val(c) == PEND_MARK;
+      const uint64_t wh = __ballot(waited && cell_key(c) != 0 && (cell_key(c) & (new_size - 1u)) == q);
+      if (wh && lane == 0 && k.old_lg + 1 >= HOME_LG) atomicOr(&row_home(arena, k.new_base, k.old_lg + 1)[q >> 6], (unsigned long long)wh);
       if (c != 0) {
-        if (cell_val(c) == PEND_MARK) { T[q] = pack_cell(cell_key(c), 0u); continue; }      // a key that waited for this doubling: {key, 0}
+        if (waited) { T[q] = pack_cell(cell_key(c), 0u); continue; }
         uint64_t o = row_cells(arena, k.old_base)[cell_val(c) - 1];
         T[q] = pack_cell(cell_key(c), cell_val(o));
         if (!twins) continue;

@@ -240,37 +240,6 @@ __device__ inline FarHit far_find(const uint8_t* arena, const uint64_t* cells, u
   if (vk.z != FAR_NOT_FOUND) return FarHit{FAR_FOUND, vk.z, nullptr, e, nullptr};
   return FarHit{FAR_ABSENT, 0u, ah->far_occ + (size_t)first_unit * FAR_UNIT_WORDS, e, ah->far_zeros + first_unit};
 }
-// ONE LANE's probe by the occupancy words of its row (the key was absent at the scan): the first cell at/after `pos`
-// (cyclically) that was free then and is empty or holds Y now; PROBE_NONE after a full turn.  Units without a free cell are
-// stepped over by their counts, so a key that wraps onto a 60 000-cell run costs ~120 loads, not 60 000 -- and 64 lanes do
-// their walks side by side, where the wave-cooperative probe took one op's at a time.
-// bits_only: the first cell that was free at the scan, whatever it holds now (the op that inserts by rank: nobody else inserts
-// its key, so the cells that others have filled since the scan -- a hot front grows by thousands of cells during the pass, and
-// looking at them one by one was 400 us for the slowest lane of a wave -- need not be looked at).
-__device__ inline uint32_t far_walk(const uint64_t* cells, uint32_t mask, const unsigned long long* occ, const uint32_t* zeros, uint32_t Y, uint32_t pos,
-                                    bool bits_only = false) {
-  const uint32_t nwords = (mask + 1u) >> 6, wmask = nwords - 1u;
-  uint32_t w = pos >> 6;
-  unsigned long long z = ~occ[w] & (~0ull << (pos & 63u));
-  for (uint32_t walked = 0; walked <= nwords + FAR_UNIT_WORDS;) {
-    if (z) {
-      const uint32_t p = (w << 6) + (uint32_t)__ffsll(z) - 1u;
-      if (bits_only) return p;
-      const uint64_t c = ld_relaxed(&cells[p]);
-      if (c == 0 || cell_key(c) == Y) return p;
-      z &= z - 1;                                      // taken since the scan by another key: on
-      continue;
-    }
-    w = (w + 1) & wmask;
-    walked++;
-    if ((w & (FAR_UNIT_WORDS - 1u)) == 0) {            // a unit begins: those without a free cell are stepped over whole
-      while (walked <= nwords + FAR_UNIT_WORDS && zeros[w >> (FAR_UNIT_LG - 6)] == 0) { w = (w + FAR_UNIT_WORDS) & wmask; walked += FAR_UNIT_WORDS; }
-    }
-    z = ~occ[w];
-  }
-  return PROBE_NONE;
-}
-
 // CLAIMED inserts of the far join.  The new far keys of a clustered row all walk to the same free cells -- the holes of their run,
 // then the cells behind it -- and each insert must see the one before it: 2 000 new keys of one row were 2 000 dependent
 // compare-and-swaps on the cell at the front, the pass's critical path.  With the join such a key is known to be absent and the
@@ -681,10 +650,7 @@ __device__ __forceinline__ void apply_body(
     DirSlot* d = nullptr;
     // (measurement runs, SMATRIX_REST_DBG: where a wave-per-op pass with the far join spends its cycles)
     unsigned long long* tdbg = WPO && FAR ? reinterpret_cast<const ArenaHead*>(arena)->dbg : nullptr;
-    unsigned long long* hdbg = FAR && !WPO ? reinterpret_cast<const ArenaHead*>(arena)->dbg : nullptr;     // (a lane per op: how long a wave's trip takes, log2 buckets)
-    const long long h0 = hdbg ? clock64() : 0;
     const long long h0r = (WPO && !FAR && reinterpret_cast<const ArenaHead*>(arena)->dbg) ? clock64() : 0;
-    long long h_find = 0, h_walk = 0, h_ins = 0;
     long long tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
     if (tdbg) tc0 = clock64();
     if (live) {
@@ -730,10 +696,8 @@ __device__ __forceinline__ void apply_body(
     if (FAR && lp.need) {
       const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
       if (ah->far_on && !ah->twins) {
-        const long long hf0 = hdbg ? clock64() : 0;
         const FarHit fh = far_find(arena, lp.cells, Y);
-        if (hdbg) h_find = clock64() - hf0;
-        if (ah->dbg && !hdbg && (t & 63u) == 0) atomicAdd(&ah->dbg[16 + fh.state], 64ull);
+        if (ah->dbg && (t & 63u) == 0) atomicAdd(&ah->dbg[16 + fh.state], 64ull);
         far_none = fh.state != FAR_FOUND && fh.state != FAR_ABSENT;
         if (fh.state == FAR_FOUND) {
           if (has_hints) was_long = ((fh.slot - Y) & lp.mask) > PROBE_BUDGET;
@@ -749,29 +713,6 @@ __device__ __forceinline__ void apply_body(
               if (WPO && has_hints) ask_hints();              // (the op that holds the claim may have put the key in already)
               if (lp.need) { lp.need = false; deferred = true; was_long = true; }
             }
-          }
-          if (!WPO && lp.need) {
-            // a lane per op: the lane walks by the occupancy words itself (far_walk), all lanes of the wave side by side
-            lp.need = false;
-            was_long = true;
-            const long long hw0 = hdbg ? clock64() : 0;
-            const uint32_t p = far_walk(lp.cells, lp.mask, fh.occ, fh.zeros, Y, lp.pos, ranked);
-            if (hdbg) { h_walk = clock64() - hw0; atomicAdd(&hdbg[40], 1ull); atomicAdd(&hdbg[41], (unsigned long long)((p - lp.pos) & lp.mask)); atomicMax(&hdbg[42], (unsigned long long)((p - lp.pos) & lp.mask));
-                        atomicAdd(&hdbg[43 + min(meta_lg(s.x) / 4u, 5u)], 1ull); }
-            const long long hi0 = hdbg ? clock64() : 0;
-            if (p == PROBE_NONE) { deferred = (OP != OP_GET); r = 0; }
-            else if (OP != OP_GET && OP != OP_SET && ranked) {
-              // (the front = the first cell that was free at the scan: the same for every op that walks up to it, whenever it comes)
-              uint32_t where = p;
-              r = far_claim_insert<OP == OP_DECR ? OP_DECR : OP_INCR>(d, s, arena, Y, V, p, const_cast<unsigned long long*>(fh.occ), fh.zeros, const_cast<uint64_t*>(lp.cells), lp.mask, &deferred, &where);
-              p_coop = where;
-            } else {
-              r = apply_row<OP, true, 1>(d, s, arena, Y, V, p, &deferred, &lp);
-              p_coop = p;
-            }
-            occ = nullptr;
-            ranked = false;                                 // (whatever is left of this op walks the old way)
-            if (hdbg) h_ins = clock64() - hi0;
           }
           zer = fh.zeros;
         }
@@ -804,20 +745,6 @@ __device__ __forceinline__ void apply_body(
             p_coop = p;
           }
         }
-      }
-    }
-    if (hdbg) {
-      // per wave: the longest lane of each phase, and the whole trip up to here
-      long long mf = h_find, mw = h_walk, mi = h_ins;
-#pragma unroll
-      for (int dd = 32; dd >= 1; dd >>= 1) {
-        mf = max(mf, (long long)__shfl_xor((int)mf, dd)); mw = max(mw, (long long)__shfl_xor((int)mw, dd)); mi = max(mi, (long long)__shfl_xor((int)mi, dd));
-      }
-      if (__lane_id() == 0) {
-        const long long tot = clock64() - h0;
-        atomicAdd(&hdbg[20], (unsigned long long)mf); atomicAdd(&hdbg[21], (unsigned long long)mw); atomicAdd(&hdbg[22], (unsigned long long)mi);
-        atomicAdd(&hdbg[23], (unsigned long long)tot); atomicAdd(&hdbg[24], 1ull);
-        atomicMax(&hdbg[25], (unsigned long long)mw); atomicMax(&hdbg[26], (unsigned long long)mi); atomicMax(&hdbg[27], (unsigned long long)tot);
       }
     }
     if (WPO && !FAR) {
@@ -1207,18 +1134,9 @@ __global__ __launch_bounds__(256) void k_get_clu(DirSlot* dir, uint32_t dmask, u
   }
 }
 
-// The pass in front of prep when the batch's far join is there: a LANE per op again.  With the join a far op is a table look-up
-// and, for a new key, a look at a few occupancy words -- no walk worth a whole wave (k_apply_wpo: 26 us per op and wave).
-template <int OP>
-__global__ __launch_bounds__(256) void k_apply_far(
-    Ctl* ctl, DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n, const uint32_t* idx,
-    const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys,
-    const uint32_t* __restrict__ vs, uint32_t* __restrict__ out, uint32_t* defer, uint32_t st) {
-  apply_body<OP, false, 1, true>(SMX_VG, ctl, dir, dmask, arena, n, idx, xs, ys, vs, out, defer, st);
-}
-
-// ... and the same a wave per op (measured faster: 2.6 against 3.5-4.6 ms per dense-id batch -- a wave with 64 far ops still
-// takes their cooperative walks one after the other)
+// The pass in front of prep with the batch's far join at hand: a wave per op, four ops to a wave.  (A LANE per op, every lane walking
+// the occupancy words itself, was measured in round 5 -- 3.5-4.6 against 2.6 ms per dense-id batch: a wave with 64 far ops still
+// takes their cooperative walks one after the other -- and is gone with its switch.)
 #ifndef SMX_WPO_FAR_WAVES
 #define SMX_WPO_FAR_WAVES 5     /* 96 VGPRs = 5 waves per SIMD: the pass is bound by the latency of its dependent loads (4 waves 1.80 ms, 5 waves 1.52 ms, 6 waves with spills 1.82 ms) */
 #endif

@@ -706,8 +706,6 @@ struct Matrix {
   void* host_pipe = nullptr;            // HostPipe: the staging of large host-pointer batches (smatrix_apply_batch and friends)
   // the far join of a clustered write batch (smx_kernels.hpp "far join"): SMATRIX_FAR_JOIN=0 switches it off
   bool far_join = true;
-  static constexpr bool far_lanes = false;  // (rejected #48: the pass in front of prep a lane per op, every lane walking the occupancy
-                                        // words itself -- slower (4.0 against 2.8 ms per dense-id batch: a wave's trip takes as long as its slowest lane)
   DevBuf<uint4> far_tab;
   DevBuf<uint32_t> far_unit_row, far_zeros;
   DevBuf<unsigned long long> far_occ, far_occ0;
@@ -1738,16 +1736,10 @@ void run_write(Matrix* m, int op, uint32_t n, const uint32_t* x, const uint32_t*
         if (m->trace_rounds) fprintf(stderr, "[smatrix] batch %llu: the folding kernel deferred %u ops\n", (unsigned long long)m->st.batches, nd_now);
       }
       far_joined = far_join_enqueue(m, s, dl, x, y, (uint32_t)std::min<uint64_t>(est_far, cur_n));
-      if (far_joined && !m->far_lanes) {
+      if (far_joined) {
         const dim3 wgrid(65536);
         if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo_far<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
         else hipLaunchKernelGGL((k_apply_wpo_far<OP_DECR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
-      } else if (far_joined) {
-        // (SMATRIX_FAR_LANES=1, measurements: with the join a lane per op, see k_apply_far)
-        const uint32_t est = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * m->spec_nd_prev, 1u << 16), cur_n);
-        const dim3 fgrid(std::min<uint32_t>(blocks_for(est), 16384));
-        if (op == OP_INCR) hipLaunchKernelGGL((k_apply_far<OP_INCR>), fgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
-        else hipLaunchKernelGGL((k_apply_far<OP_DECR>), fgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
       } else {
       const dim3 wgrid(65536);
       if (op == OP_INCR) hipLaunchKernelGGL((k_apply_wpo<OP_INCR>), wgrid, dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, 0xFFFFFFFFu, dl, x, y, v, out, dlp, m->in_stride);
@@ -2549,14 +2541,11 @@ void smatrix_close(smatrix_t* self) {
       unsigned long long c[128];
       HIP_OK(hipMemcpy(c, m->rest_dbg, 1024, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smatrix] far join, long probes of the wave-per-op pass: not in the table %llu, cell known %llu, absent at the scan %llu\n", c[16], c[17], c[18]);
-      if (c[40] && m->far_lanes) fprintf(stderr, "[smatrix] far_walk: %llu walks, %.0f cells on average, longest %llu; by row size 2^(4k..): %llu %llu %llu %llu %llu %llu\n", c[40], c[41] / (double)c[40], c[42],
-                         c[43], c[44], c[45], c[46], c[47], c[48]);
-      if (c[24]) fprintf(stderr, "[smatrix] (lane-per-op pass: per wave trip, longest lane: join look-up / walk / insert / whole trip; then the maxima of walk, insert, trip: %llu %llu %llu)\n", c[25], c[26], c[27]);
       if (c[24]) fprintf(stderr, "[smatrix] wave-per-op pass with the join, cycles per op: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f  (%llu ops)\n",
                          c[20] / (double)c[24], c[21] / (double)c[24], c[22] / (double)c[24], c[23] / (double)c[24], 64 * c[24]);
       if (c[28]) fprintf(stderr, "[smatrix] wave-per-op pass with the join: %llu trips of more than 10^5 cycles (%.0f on average, the longest %llu, longest cooperative probe %llu); by row size 2^(4k..): %llu %llu %llu %llu %llu %llu; finished %llu, deferred %llu\n",
                          c[28], c[30] / (double)c[28], c[29], c[31], c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
-      if (c[28] && !m->far_lanes) fprintf(stderr, "[smatrix]   ... their cycles: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f\n",
+      if (c[28]) fprintf(stderr, "[smatrix]   ... their cycles: directory + lane probe %.0f, join look-up %.0f, cooperative probes %.0f, apply / insert %.0f\n",
                                           c[40] / (double)c[28], c[41] / (double)c[28], c[42] / (double)c[28], c[43] / (double)c[28]);
       if (c[98] || c[113]) fprintf(stderr, "[smatrix] claimed inserts: %llu (placed %llu, none left %llu), ticks per insert: ticket %.0f (max %llu), claim %.0f (max %llu); words %.1f (max %llu), tries %.2f | above 10^5 ticks: %llu, ticket %.0f, claim %.0f, words %.1f, tries %.1f | no ticket: %llu, %.0f ticks (max %llu)\n",
               c[98], c[104], c[105], c[96] / (double)std::max(1ull, c[98]), c[99], c[97] / (double)std::max(1ull, c[98]), c[100], c[101] / (double)std::max(1ull, c[98]), c[103], c[102] / (double)std::max(1ull, c[98]),

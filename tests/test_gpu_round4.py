@@ -200,7 +200,7 @@ def test_flush_does_not_stall_the_callers(G, oracle_mod, monkeypatch, tmp_path):
 
 @pytest.mark.parametrize("n", [(1 << 19) + 12345, (1 << 20) - 1000])
 def test_hot_column_zero_cell_in_a_retry_list_below_the_fold_threshold(G, n):
-    """Round 4: retry lists below 2^20 ops ran lane per op (SMATRIX_AGG_MIN_RETRY: lists of keys that wait for a doubling are
+    """Round 4: retry lists below 2^20 ops ran lane per op (agg_min_retry in csrc/smx_runtime.hip: lists of keys that wait for a doubling are
     mostly distinct).  But a list whose rows did not exist a round ago -- or that the bulk path handed back -- holds the
     batch's own ops: 60 % of them incr(x, 0, 1) on ONE cell here (the CF example's per-item total,
     examples/cf_recommender.c:38), which then took the column-0 compare-and-swap loop of quirk Q1 one lane at a time:
