@@ -955,7 +955,7 @@ bool far_join_enqueue(Matrix* m, hipStream_t s, const uint32_t* dl, const uint32
   hipLaunchKernelGGL(k_far_keys, dim3(std::min<uint32_t>(blocks_for(est_nd), 4096)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->dir_size - 1, m->arena.base, dl, x, y,
                      m->in_stride, m->far_tab.p, tmask, (1u << lg) / 4u, all_far ? 1u : 0u, m->far_bloom.p);
   DBG_STEP(m, s, "k_far_keys");
-  const bool place = m->far_place && !all_far;
+  const bool place = m->far_place;
   if (place) { m->far_rcnt.need((size_t)cap_units + 1); m->far_bucket.need((size_t)cap_units * FAR_BUCKET_PER_UNIT); m->far_prows.need(cap_rows); }
   hipLaunchKernelGGL(k_far_scan, dim3(std::min<uint32_t>(blocks_for((uint64_t)cap_units * 64), 32768)), dim3(256), 0, s, m->d_ctl, m->d_dir, m->far_unit_row.p, cap_units,
                      m->arena.base, m->far_tab.p, tmask, m->far_occ.p, m->far_zeros.p, m->far_occ0.p, m->far_clm.p, place ? m->far_rcnt.p : nullptr, m->far_bloom.p, m->far_unit_info.p);
@@ -1152,7 +1152,7 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   // the chunked passes of the large rows touch other rows than the in-LDS rehashes: they run on a helper stream beside
   // them, from the plan on (non-blocking stream + events: the caller's stream may be the legacy default stream, which a
   // blocking helper would serialise with -- round 1's attempt with plain streams was erratic).  Same box, 3 runs each:
-  // 2.72 -> 2.65 ms per config-2 step.  SMATRIX_GROW_FORK=0 keeps everything on the caller's stream.
+  // 2.72 -> 2.65 ms per config-2 step.
   const bool fork = m->grow_fork && n_chunked && (nk[0] || nk[1] || nk[2]);
   if (fork) HIP_OK(hipEventRecord(m->ev_fork, s));
   if (nk[0])
