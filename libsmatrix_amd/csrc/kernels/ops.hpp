@@ -72,8 +72,8 @@ __device__ inline uint32_t sub_tickets_bulk(SubCtr* subs, uint32_t k0, uint32_t 
 // (src/smatrix.c:369-377) -- in probe order.
 // Round 4: WHERE a far-from-home key sits is remembered.  Nearly all of a dense batch's long probes are HITS on keys that sat
 // thousands of cells from home the batch before as well (770 000 of 2^24 ops, ~15 000 cells each: 7 ms of wave-per-op passes
-// per step).  A direct-mapped table of {y, row base, slot} entries (the matrix allocates it when its tables turn out clustered)
-// is consulted when a probe has used up its budget, and written when a wave-cooperative probe has ended on the key.  An entry
+// per step).  A table of {y, row base, slot} entries (round 6: slots of two {tag, slot} entries; the matrix allocates it when its
+// tables turn out clustered) is consulted when a probe has used up its budget, and written when a wave-cooperative probe has ended on the key.  An entry
 // is a HINT: it counts only if the cell it names holds y in the row's CURRENT block (a doubled row has a new base; a torn or
 // overwritten entry fails the same test), and a key sits in one cell of its table -- with one exception, the twins of quirk
 // Q1: a (0, v) cell whose value returns to 0 becomes an empty cell, a key behind it can then be inserted a second time in
@@ -82,7 +82,7 @@ __device__ inline uint32_t sub_tickets_bulk(SubCtr* subs, uint32_t k0, uint32_t 
 // Unit 0 of the arena (base 0 = "no block") holds the words the kernels need for this, so that no kernel signature grows.
 struct ArenaHead {
   uint32_t y0_zeroed;     // a y == 0 write has left a (0, 0) cell (see above)
-  uint32_t hint_mask;     // entries - 1 of the hint table; 0: none
+  uint32_t hint_mask;     // slots - 1 of the hint table; 0: none
   uint4* hints;
   // a table may hold one key TWICE (grow_fixdup_one): only after a probe chain was cut -- a (0, v) cell zeroed (y0_zeroed) or a
   // value-0 key dropped by the loader (quirk Q4).  While neither has happened the duplicate checks of growth are skipped.
@@ -116,6 +116,16 @@ constexpr uint32_t HINT_BUDGET = SMX_HINT_BUDGET;        // cells a lane probes 
 __device__ inline uint32_t hint_index(uint32_t base, uint32_t Y, uint32_t hmask) {
   return fmix32(base * 0x9E3779B1u ^ Y * 0x85EBCA77u) & hmask;
 }
+// (round 6) A slot holds TWO entries {tag, cell}: the tag is a second hash of (block, key), never 0.  A tag that matches by
+// accident costs a look at a cell that holds another key -- the cell decides, never the tag.  (One entry {key, block, cell} per
+// slot until round 6: of the 50 000 gets per dense-id batch that found no hint and walked, 36 000 had lost theirs to another key.)
+__device__ inline uint32_t hint_tag(uint32_t base, uint32_t Y) {
+  return fmix32(base * 0xC2B2AE35u + Y * 0x27D4EB2Fu + 0x165667B1u) | 1u;
+}
+// the cell a slot's entries name for `tag` in a table of mask + 1 cells, or 2^32-1
+__device__ inline uint32_t hint_way(uint4 e, uint32_t tag, uint32_t mask) {
+  return e.x == tag && e.y <= mask ? e.y : e.z == tag && e.w <= mask ? e.w : 0xFFFFFFFFu;
+}
 // the slot of key Y in the table at `cells` (block `base`, `mask` + 1 cells), or 2^32-1 when no valid hint exists
 __device__ inline uint32_t hint_find(const uint8_t* arena, const uint64_t* cells, uint32_t mask, uint32_t Y) {
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
@@ -126,16 +136,21 @@ __device__ inline uint32_t hint_find(const uint8_t* arena, const uint64_t* cells
   if (hmask == 0 || Y == 0 || ah->y0_zeroed) return 0xFFFFFFFFu;
 #endif
   const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
-  const uint4 e = ah->hints[hint_index(base, Y, hmask)];
-  if (e.x != Y || e.y != base || e.z > mask) return 0xFFFFFFFFu;
-  return cell_key(cells[e.z]) == Y ? e.z : 0xFFFFFFFFu;
+  const uint32_t p = hint_way(ah->hints[hint_index(base, Y, hmask)], hint_tag(base, Y), mask);
+  if (p == 0xFFFFFFFFu) return p;
+  return cell_key(cells[p]) == Y ? p : 0xFFFFFFFFu;
 }
+// (the newest entry in front, the one it pushes back stays, the third is forgotten; racing writers may lose an entry, never
+//  invent one: a slot is written with one 16-byte store)
 __device__ inline void hint_put(const uint8_t* arena, const uint64_t* cells, uint32_t Y, uint32_t pos) {
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
   const uint32_t hmask = ah->hint_mask;
   if (hmask == 0 || Y == 0) return;
   const uint32_t base = (uint32_t)((reinterpret_cast<const uint8_t*>(cells) - arena) >> 7);
-  ah->hints[hint_index(base, Y, hmask)] = uint4{Y, base, pos, 0u};
+  const uint32_t tag = hint_tag(base, Y);
+  uint4* slot = &ah->hints[hint_index(base, Y, hmask)];
+  const uint4 e = *slot;
+  *slot = e.x == tag ? uint4{tag, pos, e.z, e.w} : uint4{tag, pos, e.x, e.y};
 }
 
 constexpr uint32_t PROBE_NONE = 0xFFFFFFFFu;
@@ -372,6 +387,9 @@ constexpr uint32_t PROBE_BUDGET = SMX_PROBE_BUDGET;
 // displaced cells costs what it cost before.
 // occ (per lane; the far join): the key was ABSENT when the row's occupancy words were written -- the whole probe goes by those
 // words (a set bit: the cell was taken then, by another key), from `pos` on.
+// U: groups of 64 candidates whose cells are loaded together (k_get_clu: 4 -- a walk over 65 000 cells of a big row's run took
+// 336 load latencies one after the other, 400 us, and the kernel's last wave is always one of those).
+template <int U = 1>
 __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t mask, uint32_t Y, uint32_t pos, bool use_home = false,
                                       const unsigned long long* occ = nullptr) {
   const uint32_t lane = __lane_id();
@@ -425,25 +443,34 @@ __device__ inline uint32_t coop_probe(bool need, const uint64_t* cells, uint32_t
           if ((int)lane >= d) incl += o;
         }
         const uint32_t excl = incl - cnt, total = (uint32_t)__shfl((int)incl, 63);
-        for (uint32_t base = 0; base < total && found == PROBE_NONE; base += 64) {  // wave-uniform
-          const uint32_t g = base + lane;
-          const bool have = g < total;
-          uint32_t own = 0;                                                  // the largest lane whose exclusive prefix is <= g
+        for (uint32_t base = 0; base < total && found == PROBE_NONE; base += 64 * U) {  // wave-uniform
+          uint32_t slot[U];
+          uint64_t c[U];
+          bool have[U];
 #pragma unroll
-          for (int st = 32; st >= 1; st >>= 1) {
-            const uint32_t v = (uint32_t)__shfl((int)excl, (int)(own + st));
-            if (v <= g) own += st;
+          for (int u = 0; u < U; u++) {
+            const uint32_t g = base + (uint32_t)u * 64u + lane;
+            have[u] = g < total;
+            uint32_t own = 0;                                                // the largest lane whose exclusive prefix is <= g
+#pragma unroll
+            for (int st = 32; st >= 1; st >>= 1) {
+              const uint32_t v = (uint32_t)__shfl((int)excl, (int)(own + st));
+              if (v <= g) own += st;
+            }
+            const uint32_t e_o = (uint32_t)__shfl((int)excl, (int)own);
+            const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(cand >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)cand, (int)own);
+            slot[u] = 0;
+            c[u] = ~0ull;
+            if (have[u]) {
+              slot[u] = ((((w0 + wd + own) & wmask) << 6) | select_bit(w_o, g - e_o)) & mb;
+              c[u] = cb[slot[u]];
+            }
           }
-          const uint32_t e_o = (uint32_t)__shfl((int)excl, (int)own);
-          const unsigned long long w_o = ((unsigned long long)(uint32_t)__shfl((int)(cand >> 32), (int)own) << 32) | (uint32_t)__shfl((int)(uint32_t)cand, (int)own);
-          uint32_t slot = 0;
-          uint64_t c = ~0ull;
-          if (have) {
-            slot = ((((w0 + wd + own) & wmask) << 6) | select_bit(w_o, g - e_o)) & mb;
-            c = cb[slot];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const uint64_t m = __ballot(have[u] && (cell_key(c[u]) == yb || c[u] == 0));
+            if (m && found == PROBE_NONE) found = (uint32_t)__shfl((int)slot[u], __ffsll((unsigned long long)m) - 1);
           }
-          const uint64_t m = __ballot(have && (cell_key(c) == yb || c == 0));
-          if (m) found = (uint32_t)__shfl((int)slot, __ffsll((unsigned long long)m) - 1);
         }
       }
     }
@@ -1080,6 +1107,9 @@ __global__ __launch_bounds__(DEDUP_THREADS) void k_dedup_keys(uint32_t n, const 
 // in the order of the reference's probe (src/smatrix.c:369-377, :299), a hint only names a cell that holds the key.
 // (Measured first: the unsettled ops compacted in LDS and run through the generic body by the first wave -- 1.2 ms: a quarter
 //  of the ops miss at home, and the second half made all their loads again.)
+#ifndef SMX_GET_WALK_U
+#define SMX_GET_WALK_U 4
+#endif
 __global__ __launch_bounds__(256) void k_get_clu(DirSlot* dir, uint32_t dmask, uint8_t* arena, uint32_t n,
                                                  const uint32_t* __restrict__ xs, const uint32_t* __restrict__ ys, uint32_t* __restrict__ out, uint32_t st) {
   const ArenaHead* ah = reinterpret_cast<const ArenaHead*>(arena);
@@ -1112,21 +1142,31 @@ __global__ __launch_bounds__(256) void k_get_clu(DirSlot* dir, uint32_t dmask, u
 #pragma unroll
           for (uint32_t i = 0; i < HINT_BUDGET; i++)
             if (!settled && (cell_key(c[i]) == Y || c[i] == 0)) { settled = true; r = cell_key(c[i]) == Y ? cell_val(c[i]) : 0u; }
-          if (!settled && ask && e.x == Y && e.y == s.z && e.z <= mask) {
-            const uint64_t ch = cells[e.z];
+          if (const uint32_t hp = !settled && ask ? hint_way(e, hint_tag(s.z, Y), mask) : 0xFFFFFFFFu; hp != 0xFFFFFFFFu) {
+            const uint64_t ch = cells[hp];
             if (cell_key(ch) == Y) { settled = true; r = cell_val(ch); }
           }
           if (!settled) lp = LongProbe{true, cells, mask, (home + 1u + HINT_BUDGET) & mask};
         }
       }
     }
-    while (__any(lp.need)) {                                                // (wave-uniform: what is left walks with the wave)
-      const uint32_t p = coop_probe(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home, nullptr);
+#ifdef SMX_GET_WALK_TIMES     /* (tools/probe/get_walkers.py: a walker's result is replaced by how long its walk took) */
+    const long long w0 = wall_clock64();
+#endif
+    // what is left walks with the wave.  (Measured, tools/probe/get_walkers.py: 19 000 walkers per 2^24-get batch of the dense-id
+    // stream, 4 us at the median -- but 200 walks above 50 us and some of 400, by cold keys far down the run of a hot row whose
+    // hint had been pushed out; the kernel's last wave is always one of them: 0.80 ms against 0.40 with no walker at all.  Two
+    // entries per hint slot, four times the slots and four groups of candidates per trip of the walk: 0.54 ms.)
+    while (__any(lp.need)) {                                                // (wave-uniform)
+      const uint32_t p = coop_probe<SMX_GET_WALK_U>(lp.need, lp.cells, lp.mask, Y, lp.pos, use_home, nullptr);
       if (lp.need) {
         lp.need = false;
         if (p != PROBE_NONE) {
           const uint64_t c = lp.cells[p];
           if (cell_key(c) == Y) { r = cell_val(c); hint_put(arena, lp.cells, Y, p); }   // remembered for the next op that names it
+#ifdef SMX_GET_WALK_TIMES
+          r = 0xFFF00000u + (uint32_t)min((long long)0xFFFFF, wall_clock64() - w0);
+#endif
         }
       }
     }

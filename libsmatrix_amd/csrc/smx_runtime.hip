@@ -690,10 +690,11 @@ struct Matrix {
   // clustered rows: set for good once a batch has shown long probe sequences (dense ids); SMATRIX_CLUSTERED=1 / 0 forces it
   bool clustered = false, clustered_forced = false;
   uint32_t clustered_quiet = 0;         // chained batches in a row whose (sampled) count of long probes stayed below 1/256 of the batch
-  // where far-from-home keys sit (smx_kernels.hpp ArenaHead): 2^hint_lg entries of 16 bytes, allocated when the tables turn out
-  // clustered; SMATRIX_HINT_LG (0: no hints)
+  // where far-from-home keys sit (smx_kernels.hpp ArenaHead): 2^hint_lg slots of 16 bytes = two {tag, cell} entries each, allocated
+  // when the tables turn out clustered (256 MB; 64 MB of one-entry slots until round 6: the hot rows' cold keys lost their hints);
+  // SMATRIX_HINT_LG (0: no hints)
   uint4* d_hints = nullptr;
-  uint32_t hint_lg = 22;
+  uint32_t hint_lg = 24;
   static constexpr uint32_t wpo_max = 1u << 22;   // retry lists up to this length run a wave per op on clustered tables
   uint32_t* absent_list_dev = nullptr;  // mirror of ArenaHead::absent_list
   static constexpr bool retry_far = true;   // the long retry lists of a clustered table in host-driven rounds go through a far join of their own

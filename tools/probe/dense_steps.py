@@ -25,6 +25,7 @@ for i in range(steps):
     chk = (chk * 31 + int(o2.to(torch.int64).sum().item()) + 7 * int(o1.to(torch.int64).sum().item())) % (1 << 61)
 st = m.stats()
 print("incr/get ms per step:", " ".join("%.1f/%.1f" % t for t in ts))
+print("last 8 steps: incr %.3f ms  get %.3f ms" % (sum(a for a, b in ts[-8:]) / 8, sum(b for a, b in ts[-8:]) / 8))
 print("mean of steps 2..: %.2f ms  (%.3f G ops/s)  rounds %d long_probe_rounds %d  checksum %d" % (
     sum(a + b for a, b in ts[2:]) / (steps - 2), 2 * B / (sum(a + b for a, b in ts[2:]) / (steps - 2)) / 1e6, st["rounds"], st["long_probe_rounds"], chk), flush=True)
 m.close()
