@@ -215,6 +215,8 @@ __global__ __launch_bounds__(256) void k_pend_group(const Ctl* ctl, GrowTask* ta
 // chunk -> task maps, filled one wave per CHUNKED task (prep lists them: a steady batch has ~50 of them among 60 000
 // tasks, and a wave per task of ALL kinds made this trivial pass 40 us of the growth round's critical path)
 // arena != nullptr (clustered rows, k_grow_move_home): GrowTask::wrap_from is worked out as well
+// WRAP: the two-pass move of a clustered matrix follows (GrowTask::wrap_from is needed); without, the kernel only fills the maps
+template <bool WRAP>
 __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
                                               uint32_t* map_old, uint32_t* map_new, uint8_t* arena) {
   // one WORKGROUP per chunked task (a 2 M-slot row has 10^5 chunk entries: one wave writing them all was 30 us of the
@@ -227,39 +229,44 @@ __device__ __forceinline__ void grow_map_body(VGrid g, const Ctl* ctl, GrowTask*
     const uint32_t oc = 1u << (k.old_lg - 6), nc = 2u * oc;                          //  still mapped: the passes skip it by new_base)
     for (uint32_t c = threadIdx.x; c < oc; c += blockDim.x) map_old[k.chunk0 + c] = t;
     for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) map_new[k.chunk0_new + c] = t;
-    if (arena && k.new_base != 0) {
+    if (WRAP && arena && k.new_base != 0) {
       // GrowTask::wrap_from: the table's first run, window by window up to its first empty slot
       __shared__ uint32_t l_wrap, l_end;
       if (threadIdx.x == 0) { l_wrap = 0xFFFFFFFFu; l_end = 0xFFFFFFFFu; }
       __syncthreads();
       const uint64_t* O = row_cells(arena, k.old_base);
       const uint32_t old_size = 1u << k.old_lg;
-      // (eight windows per turn: a dense row's first run is 10^5 cells -- 400 turns of two barriers were 0.2 ms of the round's critical path)
-      for (uint32_t b0 = 0; b0 < old_size; b0 += 8u * blockDim.x) {            // block-uniform (chunked rows: old_size is a multiple of 8 x 256)
-        uint64_t c[8];
+      // (one window first -- a scrambled row's first empty slot is in it --, then eight per turn: a dense row's first run is 10^5
+      //  cells, and 400 turns of two barriers were 0.2 ms of the round's critical path)
+      auto turn = [&](auto nw, uint32_t b0) -> bool {                           // (block-uniform)
+        constexpr uint32_t W = decltype(nw)::value;
+        uint64_t c[W];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) c[q] = O[b0 + q * blockDim.x + threadIdx.x];
+        for (uint32_t q = 0; q < W; q++) { const uint32_t p = b0 + q * blockDim.x + threadIdx.x; c[q] = p < old_size ? O[p] : ~0ull; }
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) if (c[q] == 0) atomicMin(&l_end, b0 + q * blockDim.x + threadIdx.x);
+        for (uint32_t q = 0; q < W; q++) if (c[q] == 0) atomicMin(&l_end, b0 + q * blockDim.x + threadIdx.x);
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
+        for (uint32_t q = 0; q < W; q++) {
           const uint32_t p = b0 + q * blockDim.x + threadIdx.x;
-          if (c[q] != 0 && p < l_end && (cell_key(c[q]) & (old_size - 1u)) > p) atomicMin(&l_wrap, cell_key(c[q]) & (old_size - 1u));
+          if (c[q] != 0 && p < old_size && p < l_end && (cell_key(c[q]) & (old_size - 1u)) > p) atomicMin(&l_wrap, cell_key(c[q]) & (old_size - 1u));
         }
         const bool done = l_end != 0xFFFFFFFFu;                                   // (uniform: read between two barriers)
         __syncthreads();
-        if (done) break;
-      }
+        return done;
+      };
+      bool done = turn(std::integral_constant<uint32_t, 1>{}, 0u);
+      for (uint32_t b0 = blockDim.x; !done && b0 < old_size; b0 += 8u * blockDim.x) done = turn(std::integral_constant<uint32_t, 8>{}, b0);
       __syncthreads();
       if (threadIdx.x == 0) tasks[t].wrap_from = l_wrap;
       __syncthreads();
     }
   }
 }
+template <bool WRAP>
 __global__ __launch_bounds__(256) void k_grow_map(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
                                                   uint32_t* map_old, uint32_t* map_new, uint8_t* arena) {
-  grow_map_body(SMX_VG, ctl, tasks, list, map_old, map_new, arena);
+  grow_map_body<WRAP>(SMX_VG, ctl, tasks, list, map_old, map_new, arena);
 }
 
 // Rows whose old and new table fit in LDS are rebuilt there by one wave or one workgroup (the SCOPE).
@@ -285,7 +292,10 @@ struct WaveScope {                                   // the lanes of one wave; L
 //   l_old : 2^old_lg cells, l_tab : 2^(old_lg+1) slot indices, l_cd : {count, dup}, all private to the scope
 __device__ inline uint32_t rest_enter(unsigned long long* B, unsigned long long* S, uint32_t nw, uint32_t nmask, bool valid, uint32_t home);   // (below)
 // l_bits (round 6): room for one bit per new slot + one per 64-bit word of those, for the waiting keys of big tables
-template <typename S>
+// BITS: this instantiation may meet tables of >= 4096 new cells (k_grow_lds<1024, 13>): with rest_enter inlined the kernels of the
+// small kinds went from 18 to 93-96 registers, and the growth round of the SCRAMBLED stream from 2.52 to 2.56 ms per step
+// PEND: the matrix is clustered and its waiting keys come with the rebuild; the scrambled stream's launches are the instantiation without
+template <typename S, bool BITS = false, bool PEND = false>
 __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, uint64_t* l_old, uint32_t* l_tab,
                                               uint32_t* l_cd, const uint32_t* pend_keys = nullptr, unsigned long long* l_bits = nullptr) {
   constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -318,14 +328,14 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
   S::sync();
   // the keys that wait for this doubling (k_pend_group), behind the old cells: priority old_size + place in the bucket
   const uint32_t* pend = nullptr;
-  if (pend_keys && !twins && task->pend_cap) {
+  if (PEND && pend_keys && !twins && task->pend_cap) {
     const uint32_t n_old = l_cd[0], cap = new_size / 2u + 1u;
     const uint32_t take = n_old < cap ? min(min(task->n_pend, task->pend_cap), cap - n_old) : 0u;
     S::sync();                                       // (everybody has read the count)
     if (take) {
       pend = pend_keys + task->pend_off;
       const uint32_t nw = new_size >> 6;
-      if (l_bits && nw >= 64 && S::T >= 64) {
+      if (BITS && l_bits && nw >= 64 && S::T >= 64) {
         // tables of >= 4096 new cells: on a BITMAP of the slots the old cells took, like the cells in front of a slice
         // (rest_enter).  By priority probing the waiting keys of one run evict each other one cell at a time down the whole
         // run: 0.36 ms for the 8192-cell rows of a late dense-id batch, as long as the chunked passes beside them.
@@ -386,11 +396,11 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
     unsigned long long* hb = row_home(arena, task->new_base, old_lg + 1);
     for (uint32_t q = tid; q < new_size; q += S::T) {
       const uint32_t r = l_tab[q];
-      const uint64_t c = r == NONE ? 0ull : r >= old_size ? pack_cell(pend[r - old_size], 0u) : l_old[r];
+      const uint64_t c = r == NONE ? 0ull : PEND && r >= old_size ? pack_cell(pend[r - old_size], 0u) : l_old[r];
       T[q] = c;
       // (a waiting key that landed beyond a lane's budget is remembered: the retry asks the hint table.  Re-hinting the OLD cells
       //  that move far as well was measured -- the old table's hints die with its block -- and bought nothing: 0.31 vs 0.18 ms here)
-      if (r != NONE && r >= old_size && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);
+      if (PEND && r != NONE && r >= old_size && ((q - cell_key(c)) & nmask) > HINT_BUDGET) hint_put(arena, T, cell_key(c), q);
       if (bits) {
         const uint64_t hm = __ballot(c != 0 && cell_key(c) != 0 && (cell_key(c) & nmask) == q);
         if ((q & 63u) == 0) hb[q >> 6] = hm;
@@ -409,7 +419,7 @@ __device__ __forceinline__ void grow_lds_task(GrowTask* task, uint8_t* arena, ui
 
 __host__ __device__ inline size_t grow_lds_bytes(uint32_t max_lg) { return ((size_t)16 << max_lg) + ((size_t)2 << max_lg) / 8 + 64; }
 // one workgroup (THREADS = 64: one wave) per task of the given kind
-template <int THREADS, uint32_t MAX_LG>
+template <int THREADS, uint32_t MAX_LG, bool PEND>
 __global__ __launch_bounds__(THREADS) void k_grow_lds(const Ctl* ctl, GrowTask* tasks, const uint32_t* list,
                                                       uint32_t kind, uint8_t* arena, const uint32_t* pend_keys) {
   extern __shared__ uint64_t l_dyn[];                               // 2^MAX_LG cells ...
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(THREADS) void k_grow_lds(const Ctl* ctl, GrowTask* 
   __shared__ uint32_t l_cd[2];
   const uint32_t n = ctl->n_kind[kind];
   for (uint32_t li = blockIdx.x; li < n; li += gridDim.x)                     // block-uniform
-    grow_lds_task<BlockScope<THREADS>>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd, pend_keys, l_bits);
+    grow_lds_task<BlockScope<THREADS>, (PEND && MAX_LG >= 12), PEND>(&tasks[list[li]], arena, l_dyn, l_tab, l_cd, pend_keys, l_bits);
 }
 
 // one wave per 64 old slots

@@ -1156,15 +1156,20 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
   // 2.72 -> 2.65 ms per config-2 step.
   const bool fork = m->grow_fork && n_chunked && (nk[0] || nk[1] || nk[2]);
   if (fork) HIP_OK(hipEventRecord(m->ev_fork, s));
-  if (nk[0])
-    hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), grow_lds_bytes(GROW_LG0), s,
-                       m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base, pend_keys);
-  if (nk[1])
-    hipLaunchKernelGGL((k_grow_lds<256, GROW_LG1>), dim3(std::min<uint32_t>(nk[1], 4096)), dim3(256), grow_lds_bytes(GROW_LG1), s,
-                       m->d_ctl, m->tasks.p, m->klist.p + m->klist_cap, 1u, m->arena.base, pend_keys);
-  if (nk[2])
-    hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), grow_lds_bytes(GROW_LG2), s,
-                       m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base, pend_keys);
+  // (a clustered matrix's rebuilds take the waiting keys in: their own instantiation -- the scrambled stream's launches stay round 5's code)
+  auto lds_kinds = [&](auto pend_c) {
+    constexpr bool P = decltype(pend_c)::value;
+    if (nk[0])
+      hipLaunchKernelGGL((k_grow_lds<64, GROW_LG0, P>), dim3(std::min<uint32_t>(nk[0], 32768)), dim3(64), grow_lds_bytes(GROW_LG0), s,
+                         m->d_ctl, m->tasks.p, m->klist.p, 0u, m->arena.base, pend_keys);
+    if (nk[1])
+      hipLaunchKernelGGL((k_grow_lds<256, GROW_LG1, P>), dim3(std::min<uint32_t>(nk[1], 4096)), dim3(256), grow_lds_bytes(GROW_LG1), s,
+                         m->d_ctl, m->tasks.p, m->klist.p + m->klist_cap, 1u, m->arena.base, pend_keys);
+    if (nk[2])
+      hipLaunchKernelGGL((k_grow_lds<1024, GROW_LG2, P>), dim3(std::min<uint32_t>(nk[2], 1024)), dim3(1024), grow_lds_bytes(GROW_LG2), s,
+                         m->d_ctl, m->tasks.p, m->klist.p + 2 * (size_t)m->klist_cap, 2u, m->arena.base, pend_keys);
+  };
+  if (pend_keys) lds_kinds(std::true_type{}); else lds_kinds(std::false_type{});
   DBG_STEP(m, s, "k_grow_lds x3");
   const uint64_t oc_bound = (uint64_t)n_chunked + gu / 8, nc_bound = (uint64_t)n_chunked + gu / 4;
   hipStream_t sc = s;
@@ -1179,9 +1184,12 @@ void grow_rows(Matrix* m, hipStream_t s, uint32_t nt, uint64_t gu, const uint32_
     // (the first pass leaves the new tables' at-home bitmaps behind their blocks: the second pass, the duplicate check and,
     //  from then on, the op kernels' long probes step over at-home cells by them -- smx_kernels.hpp HOME_LG)
     const bool two_pass = m->clustered && m->home_on;
-    hipLaunchKernelGGL(k_grow_map, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 2048)),
-                       dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p,
-                       two_pass ? m->arena.base : nullptr);
+    if (two_pass)
+      hipLaunchKernelGGL(k_grow_map<true>, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 2048)),
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p, m->arena.base);
+    else
+      hipLaunchKernelGGL(k_grow_map<false>, dim3(std::min<uint32_t>(std::max<uint32_t>(n_chunked, 1), 2048)),
+                         dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->klist.p + 3 * (size_t)m->klist_cap, m->map_old.p, m->map_new.p, nullptr);
     if (two_pass) {
       hipLaunchKernelGGL(k_grow_move_home, dim3(std::min<uint32_t>(blocks_for(oc_bound * 64), 16384)),
                          dim3(256), 0, sc, m->d_ctl, m->tasks.p, m->map_old.p, m->arena.base, m->rest_lds ? m->disp_mask.p : nullptr);
@@ -2479,7 +2487,9 @@ smatrix_t* smatrix_open(const char* fname) {
   }
   HIP_OK(hipStreamSynchronize(m->stream));
   ctl_push_persistent(m, m->stream);
-  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2>),
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)grow_lds_bytes(GROW_LG2)));
+  HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_lds<1024, GROW_LG2, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)grow_lds_bytes(GROW_LG2)));
   HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grow_rest_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rest_lds_bytes()));
   if (const char* a = getenv("SMATRIX_REST_LDS")) m->rest_lds = *a != '0';
